@@ -1,0 +1,280 @@
+/*
+ * v4ray_hip.h -- C ABI of the gfx950 wavefront path tracer.
+ *
+ * This is the boundary a host (the reference's Rust crate, this repository's C++ host, or
+ * Python/ctypes) binds.  The host flattens its scene into the plain SoA tables of
+ * `v4r_scene_desc`; `v4r_renderer_create` copies them into HBM (the caller keeps ownership of
+ * every pointer it passes) and the render entry points run hand-written HIP kernels on them.
+ *
+ * Every function returns 0 (V4R_OK) or a negative V4R_E_* code and never aborts the process;
+ * `v4r_last_error()` returns a thread-local description of the last failure.  Calls on one
+ * renderer handle are serialised on that handle's HIP stream; different handles are independent.
+ *
+ * Each declaration cites the reference interface (file:line under the reference tree) it replaces.
+ */
+#ifndef V4RAY_HIP_H
+#define V4RAY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define V4R_ABI_VERSION 1u
+
+/* ---- status codes ------------------------------------------------------------------------- */
+#define V4R_OK 0
+#define V4R_E_INVALID (-1)     /* bad argument / malformed scene table                         */
+#define V4R_E_NO_DEVICE (-2)   /* no usable gfx950 device / HIP runtime failure at set-up       */
+#define V4R_E_HIP (-3)         /* a HIP call failed (message in v4r_last_error)                 */
+#define V4R_E_UNSUPPORTED (-4) /* scene uses a feature the device path does not implement       */
+#define V4R_E_LIMIT (-5)       /* a size exceeds a documented limit (e.g. BVH depth > stack)    */
+
+/* ---- geometry tables ---------------------------------------------------------------------- */
+
+/* Leaf marker in v4r_bvh_node::child*: MSB set => low 31 bits are a primitive index. */
+#define V4R_LEAF_BIT 0x80000000u
+
+/* One interior BVH node, 64 bytes, holding BOTH children's boxes (as src/bvh/bvh.rs:13-16 does).
+ * Leaves of the reference tree (bvh.rs:10-12, one shape each) are folded into the child words. */
+typedef struct v4r_bvh_node {
+    float lo0[3], hi0[3]; /* AABB of child 0 (src/bvh/aabb.rs:9-12) */
+    float lo1[3], hi1[3]; /* AABB of child 1 */
+    uint32_t child0, child1;
+    uint32_t pad[2];
+} v4r_bvh_node;
+
+/* Primitive kinds (src/hittable/{sphere,aa_rect,triangle,constant_medium}.rs). */
+enum {
+    V4R_PRIM_SPHERE = 0,  /* f = {cx,cy,cz,r}                                   sphere.rs:27-30   */
+    V4R_PRIM_XY_RECT = 1, /* f = {x0,x1,y0,y1,k(z)}                             aa_rect.rs:190    */
+    V4R_PRIM_YZ_RECT = 2, /* f = {y0,y1,z0,z1,k(x)}                             aa_rect.rs:191    */
+    V4R_PRIM_ZX_RECT = 3, /* f = {z0,z1,x0,x1,k(y)}                             aa_rect.rs:192    */
+    V4R_PRIM_TRIANGLE = 4,/* f = {v0.xyz, edge12.xyz, edge13.xyz}; aux -> tri_shading  triangle.rs:11-18 */
+    V4R_PRIM_MEDIUM = 5   /* aux -> media[]                                     constant_medium.rs:11-14 */
+};
+#define V4R_PRIM_TYPE_MASK 0xFFu
+#define V4R_PRIM_POSITIVE 0x100u /* rect `positive` flag (aa_rect.rs:87) */
+#define V4R_NO_XFORM 0xFFFFFFFFu
+
+/* 48-byte primitive record; prims[i] pairs with prim_material[i] exactly like
+ * Scene::hittables[i] / Scene::materials[i] (src/scene.rs:20-23). */
+typedef struct v4r_prim {
+    float f[9];
+    uint32_t type;  /* V4R_PRIM_* | flags */
+    uint32_t xform; /* index into xforms[] or V4R_NO_XFORM (TransformHittable, transform.rs:8-14) */
+    uint32_t aux;
+} v4r_prim;
+
+/* Affine wrapper, row-major 3x3 + translation, forward and inverse (transform.rs:8-14). */
+typedef struct v4r_xform {
+    float fwd[9], fwd_t[3];
+    float inv[9], inv_t[3];
+} v4r_xform;
+
+/* Per-triangle shading data (triangle.rs:13-14): vertex normals and uvs. 64 bytes. */
+typedef struct v4r_tri_shading {
+    float n[3][3];
+    float uv[3][2];
+    float pad;
+} v4r_tri_shading;
+
+/* ConstantMedium (constant_medium.rs:11-22): boundary = medium_prims[first .. first+count)
+ * (count > 1 is a HittableGroup boundary, hittables/group.rs:58-67). */
+typedef struct v4r_medium {
+    uint32_t first, count;
+    float neg_inv_density;
+    uint32_t pad;
+} v4r_medium;
+
+/* ---- appearance tables -------------------------------------------------------------------- */
+enum {
+    V4R_MAT_LAMBERTIAN = 0,   /* tex                 material/lambertian.rs:21-23 */
+    V4R_MAT_METAL = 1,        /* albedo, fuzz        material/metal.rs:15-18      */
+    V4R_MAT_DIELECTRIC = 2,   /* ir                  material/dielectric.rs:13-15 */
+    V4R_MAT_DIFFUSE_LIGHT = 3,/* tex (emit)          material/diffuse_light.rs:8-10 */
+    V4R_MAT_ISOTROPIC = 4     /* tex (albedo)        material/isotropic.rs:11-13  */
+};
+typedef struct v4r_material {
+    uint32_t kind;
+    uint32_t tex;
+    float albedo[3];
+    float fuzz;
+    float ir;
+    uint32_t pad;
+} v4r_material;
+
+enum {
+    V4R_TEX_SOLID = 0,   /* color                          texture/solid_color.rs:11-13 */
+    V4R_TEX_CHECKER = 1, /* a = odd tex, b = even tex, s = density   texture/checker.rs:15-19 */
+    V4R_TEX_IMAGE = 2,   /* a = image index                texture/image.rs:9-11        */
+    V4R_TEX_NOISE = 3    /* a = perlin table, b = depth, s = scale   texture/noise.rs:144-148 */
+};
+typedef struct v4r_texture {
+    uint32_t kind;
+    float color[3];
+    float s;
+    uint32_t a, b;
+    uint32_t pad;
+} v4r_texture;
+
+/* 8-bit RGB image, rows top to bottom, 3 bytes per texel, at texels + offset. */
+typedef struct v4r_image {
+    uint64_t offset;
+    uint32_t width, height;
+} v4r_image;
+
+/* One Perlin table set (texture/noise.rs:13-18). */
+typedef struct v4r_perlin {
+    float vec[256][3];
+    uint8_t perm_x[256], perm_y[256], perm_z[256];
+} v4r_perlin;
+
+/* Camera state after Camera::new (src/camera.rs:65-75). */
+typedef struct v4r_camera {
+    float origin[3], lower_left_corner[3], horizontal[3], vertical[3], u[3], v[3];
+    float lens_radius, time0, time1;
+} v4r_camera;
+
+/* Scene flags. */
+#define V4R_FLAG_BOUNDED_LIGHT_PDF 0x1u /* rect/triangle light pdf is 0 for directions that miss the
+                                           light (textbook); default off = the reference's packet
+                                           behaviour (aa_rect.rs:158-179, triangle.rs:110-131)   */
+
+/* Flattened scene + renderer parameters.  All pointers are host pointers, copied by
+ * v4r_renderer_create; a table with n == 0 may be NULL. */
+typedef struct v4r_scene_desc {
+    uint32_t abi_version; /* V4R_ABI_VERSION */
+    uint32_t flags;
+
+    uint32_t n_nodes;
+    uint32_t bvh_depth; /* max number of interior nodes on a root-to-leaf path (0 if n_nodes==0) */
+    const v4r_bvh_node *nodes; /* node 0 is the root; n_prims == 1 => n_nodes == 0 */
+
+    uint32_t n_prims;
+    uint32_t n_xforms;
+    const v4r_prim *prims;
+    const uint32_t *prim_material; /* material index per primitive */
+    const v4r_xform *xforms;
+
+    uint32_t n_tri_shading;
+    uint32_t n_media;
+    const v4r_tri_shading *tri_shading;
+    const v4r_medium *media;
+    uint32_t n_medium_prims;
+    uint32_t n_materials;
+    const v4r_prim *medium_prims;
+    const v4r_material *materials;
+
+    uint32_t n_textures;
+    uint32_t n_images;
+    const v4r_texture *textures;
+    const v4r_image *images;
+    const uint8_t *texels;
+    uint64_t texel_bytes;
+
+    uint32_t n_perlin;
+    uint32_t n_lights;
+    const v4r_perlin *perlin;
+    const uint32_t *lights; /* primitive indices of the `important` objects (scene.rs:52-61) */
+
+    float background[3];  /* colour of any miss (renderer.rs:184)              */
+    float environment[3]; /* colour returned when the depth budget hits 0 (renderer.rs:128-130) */
+    v4r_camera camera;
+
+    uint32_t width, height; /* RendererParam (renderer.rs:44-51) */
+    uint32_t max_depth;     /* already defaulted (20 when absent, renderer.rs:331) */
+    uint32_t antialias;     /* 0 = pixel centres (renderer.rs:103-104), else jittered */
+} v4r_scene_desc;
+
+typedef struct v4r_renderer v4r_renderer;
+
+/* Work counters of the traversal stage, summed over every ray segment traced while counting
+ * is enabled; they feed the algorithmic-bytes figure of the roofline report. */
+typedef struct v4r_stats {
+    uint64_t segments;     /* rays traced (one per path segment)         */
+    uint64_t nodes;        /* 64-byte BVH nodes fetched                  */
+    uint64_t prims;        /* 48-byte primitive records intersected      */
+    uint64_t paths;        /* camera paths started                       */
+    uint64_t shaded;       /* hit records shaded                         */
+    uint64_t texel_fetches;/* image-texture texels fetched               */
+} v4r_stats;
+
+/* ---- entry points ------------------------------------------------------------------------- */
+
+/* Build a renderer on HIP device `device`: validates and uploads the tables, allocates the
+ * wavefront queues and a zeroed (H,W,3) fp32 accumulator.
+ * Replaces Renderer::new (src/renderer.rs:84-93) -- BVH construction stays with the host. */
+int v4r_renderer_create(const v4r_scene_desc *desc, int device, v4r_renderer **out);
+
+/* Replaces dropping the Arc<Renderer> (src/main.rs:35). NULL is accepted. */
+void v4r_renderer_destroy(v4r_renderer *r);
+
+/* Render passes first_pass, first_pass+pass_stride, ... (n_passes of them), each a full-image
+ * 1-sample-per-pixel pass, and add them into the device accumulator.  Asynchronous on the
+ * renderer's stream.  Pass p uses random stream (seed, p, pixel, bounce, dimension), so a job
+ * split over N ranks as first_pass = rank, pass_stride = N consumes the same streams as N = 1.
+ * Replaces Renderer::render (src/renderer.rs:321-332) followed by RenderResult::add (:355-368). */
+int v4r_render(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_t pass_stride,
+               uint32_t n_passes);
+
+/* Use caller-owned device memory (H*W*3 floats, e.g. a framework tensor that a collective will
+ * reduce) as the accumulator from now on; NULL restores the renderer's own buffer.  The buffer is
+ * not cleared.  No counterpart in the reference (its accumulator is the RwLock'd Vec of
+ * src/renderer.rs:336-340). */
+int v4r_accum_bind(v4r_renderer *r, float *device_hwc);
+
+/* Zero the accumulator and the pass count. Replaces RenderResult::new (src/renderer.rs:343-354). */
+int v4r_accum_clear(v4r_renderer *r);
+
+/* Synchronise, then copy the (H,W,3) fp32 radiance sums (row 0 = top) to host memory and report how
+ * many passes they hold.  Either pointer may be NULL.  Replaces the Vec<f32> hand-off of
+ * PyRenderer::py_render (src/renderer.rs:450-476). */
+int v4r_accum_read(v4r_renderer *r, float *host_hwc, uint32_t *n_passes);
+
+/* Device address and length (floats) of the accumulator currently bound, for an RCCL reduce
+ * issued by the caller after v4r_synchronize. */
+int v4r_accum_device(v4r_renderer *r, float **device_hwc, uint64_t *n_floats);
+
+/* 8-bit image of accumulator / n_passes: u8(clamp(256*sqrt(x), 0.5, 255.5)), NaN -> 0.
+ * Replaces RenderResult::get_raw (src/renderer.rs:369-406). */
+int v4r_tonemap_u8(v4r_renderer *r, uint32_t n_passes, uint8_t *host_rgb);
+
+/* Parity gate: trace the W*H deterministic primary rays (pixel centres, no lens sample, time0)
+ * and return the closest primitive index (0xFFFFFFFF = miss) and hit distance per pixel,
+ * row 0 = top.  Maps to BVH::traverse (src/bvh/bvh.rs:182-239) + the closest-hit selection of
+ * Renderer::ray_color (src/renderer.rs:149-183) for depth-0 rays. */
+int v4r_trace_primary(v4r_renderer *r, uint32_t *host_prim_id, float *host_t);
+
+/* Trace n caller-supplied rays (origins and unit directions as n x 3 floats, optional time) and
+ * return closest primitive / t per ray. `seed` keys the stochastic constant-medium test.
+ * Maps to BVH::traverse + Hittable::hit (src/hittable/mod.rs:180-182). */
+int v4r_trace_rays(v4r_renderer *r, uint32_t n, const float *host_origin, const float *host_dir,
+                   uint64_t seed, uint32_t *host_prim_id, float *host_t);
+
+/* Enable/disable the traversal work counters (an instrumented kernel variant) and read them. */
+int v4r_stats_enable(v4r_renderer *r, int on);
+int v4r_stats_read(v4r_renderer *r, v4r_stats *out, int reset);
+
+/* Block until every queued pass has finished. */
+int v4r_synchronize(v4r_renderer *r);
+
+/* The HIP stream (hipStream_t) the renderer launches on, so callers can order their own work
+ * (events, collectives) against it. */
+int v4r_stream(v4r_renderer *r, void **hip_stream);
+
+/* Number of passes held by the accumulator (RenderResult.1, src/renderer.rs:366-367). */
+int v4r_pass_count(v4r_renderer *r, uint32_t *n_passes);
+
+/* Thread-local message for the last non-zero status. Replaces the reference's panics
+ * (src/json.rs:351-353, src/main.rs:71). */
+const char *v4r_last_error(void);
+
+uint32_t v4r_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* V4RAY_HIP_H */

@@ -1,0 +1,1041 @@
+// v4r_oracle.cpp -- CPU restatement of the reference's render loop.  TEST INFRASTRUCTURE ONLY.
+//
+// This file is the checker for the HIP path: only tests/, __graft_entry__.smoke() and the
+// cpu_baseline leg of bench.py may build, load or call it.  Nothing the product ships links it.
+//
+// It restates, one scalar ray at a time and in f32 with one rounding per operation (build with
+// -ffp-contract=off), the arithmetic of the reference's Renderer::render -> ray_color path and
+// everything that path calls; every function cites the reference file:line it follows
+// (paths are relative to the reference tree's src/).
+//
+// Pinning status -- "parity unpinned": the reference ships no tests, golden vectors or fixtures,
+// and it can be neither compiled (nightly Rust + un-vendored crates) nor imported (its extension
+// module was never built) in the build environment.  The oracle is therefore pinned only by
+// closed-form known-answer tests written from the reference's formulas (tests/test_oracle_kat.py).
+// Third-party arithmetic the reference relies on (nalgebra Rotation3::face_towards, simba
+// packed_simd comparisons/transcendentals, rand's gen_range) is restated from those crates'
+// published definitions.
+//
+// Deliberate, documented departures (none changes the estimator):
+//  * Random numbers: the reference draws from an OS-seeded ThreadRng (random.rs:6-16), which is
+//    irreproducible.  Here every draw is a pure function of (seed, pass, pixel, segment,
+//    dimension) -- the same counter-based generator the device uses -- so oracle and device
+//    trace the same paths and can be compared per pixel.
+//  * Packets: the reference processes 8 rays per SIMD packet.  Per-lane results do not depend
+//    on the other lanes except in Samplable::value for rectangles and triangles
+//    (aa_rect.rs:158-179, triangle.rs:110-131), where a lane that misses the light still gets
+//    the un-clipped plane density whenever ANY lane of its packet hits.  Scalar restatement:
+//    the plane density always (default), or the textbook bounded density under
+//    V4R_FLAG_BOUNDED_LIGHT_PDF.
+//  * Recursion: ray_color's breadth-first recursion (renderer.rs:123-320) is run per path as a
+//    loop carrying the product of the per-bounce coefficients; colour = emitted + coef * child
+//    unrolls to the same sum of products.
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "v4ray_hip.h"
+
+namespace {
+
+constexpr float EPSILON = 0.001f;  // lib.rs:34
+constexpr float INF = std::numeric_limits<float>::infinity();
+constexpr float PI = 3.14159265358979323846f;
+constexpr float TWO_PI = 6.28318530717958647692f;
+constexpr float FRAC_1_PI = 0.318309886183790671538f;
+
+thread_local std::string g_error;
+
+// ---- vectors ------------------------------------------------------------------------------------
+struct V3 {
+    float x, y, z;
+    float operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+};
+inline V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+inline V3 v3(const float *p) { return V3{p[0], p[1], p[2]}; }
+inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator-(V3 a) { return {-a.x, -a.y, -a.z}; }
+inline V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+inline V3 operator*(V3 a, V3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+inline V3 operator/(V3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline float norm2(V3 a) { return dot(a, a); }
+inline float norm(V3 a) { return std::sqrt(norm2(a)); }
+inline V3 normalize(V3 a) { return a / norm(a); }  // Unit::new_normalize
+inline V3 mat_mul(const float *m, V3 v) {          // row-major 3x3
+    return {m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z,
+            m[6] * v.x + m[7] * v.y + m[8] * v.z};
+}
+
+// ---- counter-based random numbers (replaces random.rs:6-16) ---------------------------------------
+// mix: a 32-bit finaliser with full avalanche.  A path key is derived from (seed, pass, pixel);
+// each path segment derives a segment key; a draw hashes (segment key, dimension).
+inline uint32_t mix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+struct PathKey {
+    uint32_t k0, k1;
+};
+inline PathKey path_key(uint64_t seed, uint32_t pass, uint32_t pixel) {
+    uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
+    PathKey k;
+    k.k0 = mix32(pixel + mix32(pass + mix32(lo)));
+    k.k1 = mix32(pass ^ mix32(pixel ^ mix32(hi ^ 0x9E3779B9u)));
+    return k;
+}
+inline uint32_t segment_key(PathKey k, uint32_t segment) { return mix32(k.k0 + segment * 0x9E3779B9u) ^ k.k1; }
+inline uint32_t draw_u32(uint32_t seg_key, uint32_t dim) { return mix32(seg_key + dim * 0x85EBCA6Bu); }
+inline float draw(uint32_t seg_key, uint32_t dim) { return (float)(draw_u32(seg_key, dim) >> 8) * (1.0f / 16777216.0f); }
+inline float draw_range(uint32_t seg_key, uint32_t dim, float lo, float hi) { return lo + (hi - lo) * draw(seg_key, dim); }
+
+// dimension assignment within a segment
+enum {
+    DIM_PIXEL_X = 0,
+    DIM_PIXEL_Y = 1,
+    DIM_LENS_R = 2,
+    DIM_LENS_THETA = 3,
+    DIM_TIME = 4,
+    DIM_SCATTER = 8,  // 8..15: material / pdf sampling at the end of the segment
+    DIM_MEDIUM = 32   // 32..63: constant-medium free-path draw, + (primitive index & 31)
+};
+
+// ---- scene view ---------------------------------------------------------------------------------
+struct Ray {
+    V3 o, d;
+};
+
+struct Hit {  // HitRecord, hittable/mod.rs:24-32
+    V3 p{0, 0, 0};
+    V3 normal{0, 1, 0};
+    float t = INF;
+    float u = 0, v = 0;
+    bool front_face = false;
+    bool mask = false;
+};
+
+struct Counters {
+    uint64_t segments = 0, nodes = 0, prims = 0, paths = 0, shaded = 0, texels = 0;
+    void add(const Counters &o) {
+        segments += o.segments;
+        nodes += o.nodes;
+        prims += o.prims;
+        paths += o.paths;
+        shaded += o.shaded;
+        texels += o.texels;
+    }
+};
+
+struct Ctx {
+    const v4r_scene_desc *s;
+    uint32_t seg_key = 0;  // key of the segment being traced / shaded
+    Counters cnt;
+};
+
+// HitRecord::face_normal, hittable/mod.rs:146-154 (is_simd_negative on packed f32 is `< 0`)
+inline void face_normal(V3 dir, V3 outward, bool &front, V3 &normal) {
+    front = dot(dir, outward) < 0.0f;
+    normal = front ? outward : -outward;
+}
+
+// sphere_uv, hittable/sphere.rs:38-45
+inline void sphere_uv(V3 p, float &u, float &v) {
+    float theta = std::acos(-p.y);
+    float phi = std::atan2(-p.z, p.x) + PI;
+    u = phi / TWO_PI;
+    v = theta * FRAC_1_PI;
+}
+
+// Sphere::hit, hittable/sphere.rs:60-93
+Hit hit_sphere(const float *f, const Ray &r, float t_min, float t_max) {
+    Hit h;
+    V3 center = v3(f);
+    float radius = f[3];
+    V3 oc = r.o - center;
+    float half_b = dot(oc, r.d);
+    float c = norm2(oc) - radius * radius;
+    float disc = half_b * half_b - c;
+    if (disc < 0.0f) return h;
+    float sqrt_d = std::sqrt(disc);
+    float root1 = -half_b - sqrt_d;
+    bool m1 = root1 >= t_min && root1 <= t_max;
+    float root2 = -half_b + sqrt_d;
+    bool m2 = root2 >= t_min && root2 <= t_max;
+    if (!(m1 || m2)) return h;
+    float t = m1 ? root1 : root2;
+    V3 p = r.o + r.d * t;
+    V3 outward = normalize(p - center);
+    face_normal(r.d, outward, h.front_face, h.normal);
+    sphere_uv(outward, h.u, h.v);
+    h.p = p;
+    h.t = t;
+    h.mask = true;
+    return h;
+}
+
+// axis triple of a rect type: a-axis, b-axis, k-axis  (aa_rect.rs:190-192)
+inline void rect_axes(uint32_t type, int &ia, int &ib, int &ik) {
+    switch (type & V4R_PRIM_TYPE_MASK) {
+        case V4R_PRIM_XY_RECT: ia = 0; ib = 1; ik = 2; break;
+        case V4R_PRIM_YZ_RECT: ia = 1; ib = 2; ik = 0; break;
+        default: ia = 2; ib = 0; ik = 1; break;  // ZX
+    }
+}
+inline V3 axis_vec(int axis, float s) { return axis == 0 ? v3(s, 0, 0) : (axis == 1 ? v3(0, s, 0) : v3(0, 0, s)); }
+
+// $ty::hit, hittable/aa_rect.rs:114-144.  `fields_only` keeps computing t / normal after a failed
+// range or bounds test, which is what a SIMD lane sees when another lane of its packet hits.
+Hit hit_rect(const v4r_prim &pr, const Ray &r, float t_min, float t_max, bool fields_only = false) {
+    Hit h;
+    int ia, ib, ik;
+    rect_axes(pr.type, ia, ib, ik);
+    const float *f = pr.f;
+    float t = (f[4] - r.o[ik]) / r.d[ik];
+    bool mask = t >= t_min && t <= t_max;
+    if (!mask && !fields_only) return h;
+    float a = r.o[ia] + t * r.d[ia];
+    float b = r.o[ib] + t * r.d[ib];
+    mask = mask && a >= f[0] && a <= f[1] && b >= f[2] && b <= f[3];
+    if (!mask && !fields_only) return h;
+    h.u = (a - f[0]) / (f[1] - f[0]);
+    h.v = (b - f[2]) / (f[3] - f[2]);
+    V3 outward = axis_vec(ik, (pr.type & V4R_PRIM_POSITIVE) ? 1.0f : -1.0f);  // rect_norm!, aa_rect.rs:9-31
+    face_normal(r.d, outward, h.front_face, h.normal);
+    h.p = r.o + r.d * t;
+    h.t = t;
+    h.mask = mask;
+    return h;
+}
+
+// Triangle::hit, hittable/triangle.rs:56-96
+Hit hit_triangle(const v4r_prim &pr, const v4r_tri_shading &ts, const Ray &r, float t_min, float t_max,
+                 bool fields_only = false) {
+    Hit h;
+    V3 v0 = v3(pr.f), e12 = v3(pr.f + 3), e13 = v3(pr.f + 6);
+    V3 p_vec = cross(r.d, e13);
+    float det = dot(e12, p_vec);
+    bool mask = std::fabs(det) > 0.0f;
+    if (!mask && !fields_only) return h;
+    float inv_det = 1.0f / det;
+    V3 t_vec = r.o - v0;
+    float u = inv_det * dot(t_vec, p_vec);
+    mask = mask && !(u < 0.0f) && u <= 1.0f;
+    if (!mask && !fields_only) return h;
+    V3 q_vec = cross(t_vec, e12);
+    float v = inv_det * dot(r.d, q_vec);
+    mask = mask && !(v < 0.0f) && (u + v) <= 1.0f;
+    if (!mask && !fields_only) return h;
+    float t = inv_det * dot(e13, q_vec);
+    mask = mask && t >= t_min && t <= t_max;
+    if (!mask && !fields_only) return h;
+    float w = 1.0f - u - v;
+    h.p = r.o + r.d * t;
+    h.normal = normalize(v3(ts.n[0]) * w + v3(ts.n[1]) * u + v3(ts.n[2]) * v);  // not flipped toward the ray
+    h.t = t;
+    h.u = ts.uv[0][0] * w + ts.uv[1][0] * u + ts.uv[2][0] * v;
+    h.v = ts.uv[0][1] * w + ts.uv[1][1] * u + ts.uv[2][1] * v;
+    h.front_face = det > 0.0f;
+    h.mask = mask;
+    return h;
+}
+
+Hit hit_prim(Ctx &ctx, const v4r_prim &pr, uint32_t prim_index, const Ray &r, float t_min, float t_max);
+
+// HittableGroup::hit, hittables/group.rs:58-67
+Hit hit_group(Ctx &ctx, const v4r_prim *prims, uint32_t count, uint32_t prim_index, const Ray &r, float t_min,
+              float t_max) {
+    Hit best;
+    float closest = t_max;
+    for (uint32_t i = 0; i < count; ++i) {
+        Hit h = hit_prim(ctx, prims[i], prim_index, r, t_min, closest);
+        if (h.mask) {
+            closest = h.t;
+            best = h;
+        }
+    }
+    return best;
+}
+
+// ConstantMedium::hit, hittable/constant_medium.rs:40-85
+Hit hit_medium(Ctx &ctx, const v4r_prim &pr, uint32_t prim_index, const Ray &r, float t_min, float t_max) {
+    const v4r_medium &m = ctx.s->media[pr.aux];
+    const v4r_prim *boundary = ctx.s->medium_prims + m.first;
+    Hit none;
+    Hit h1 = hit_group(ctx, boundary, m.count, prim_index, r, -INF, INF);
+    if (!h1.mask) return none;
+    Hit h2 = hit_group(ctx, boundary, m.count, prim_index, r, h1.t + EPSILON, INF);
+    if (!h2.mask) return none;
+    float lo = std::fmax(h1.t, t_min);
+    float hi = std::fmin(h2.t, t_max);
+    if (!(lo < hi)) return none;
+    lo = std::fmax(lo, 0.0f);
+    float distance_inside = hi - lo;
+    float u = draw(ctx.seg_key, DIM_MEDIUM + (prim_index & 31u));
+    float hit_distance = m.neg_inv_density * std::log(u);
+    if (!(hit_distance <= distance_inside)) return none;
+    Hit h;
+    h.t = h1.t + hit_distance;
+    h.p = r.o + r.d * h.t;
+    h.normal = v3(1, 0, 0);
+    h.u = h.v = 0;
+    h.front_face = true;
+    h.mask = true;
+    return h;
+}
+
+// TransformHittable::hit, hittable/transform.rs:64-95, around any primitive kind
+Hit hit_prim(Ctx &ctx, const v4r_prim &pr, uint32_t prim_index, const Ray &r, float t_min, float t_max) {
+    Ray lr = r;
+    float nrm = 1.0f;
+    const v4r_xform *x = nullptr;
+    if (pr.xform != V4R_NO_XFORM) {
+        x = &ctx.s->xforms[pr.xform];
+        V3 dir = mat_mul(x->inv, r.d);
+        nrm = norm(dir);
+        lr.o = mat_mul(x->inv, r.o) + v3(x->inv_t);
+        lr.d = dir / nrm;
+        t_min = t_min * nrm;
+        t_max = t_max * nrm;
+    }
+    Hit h;
+    switch (pr.type & V4R_PRIM_TYPE_MASK) {
+        case V4R_PRIM_SPHERE: h = hit_sphere(pr.f, lr, t_min, t_max); break;
+        case V4R_PRIM_XY_RECT:
+        case V4R_PRIM_YZ_RECT:
+        case V4R_PRIM_ZX_RECT: h = hit_rect(pr, lr, t_min, t_max); break;
+        case V4R_PRIM_TRIANGLE: h = hit_triangle(pr, ctx.s->tri_shading[pr.aux], lr, t_min, t_max); break;
+        case V4R_PRIM_MEDIUM: h = hit_medium(ctx, pr, prim_index, lr, t_min, t_max); break;
+        default: break;
+    }
+    if (x && h.mask) {
+        h.p = mat_mul(x->fwd, h.p) + v3(x->fwd_t);
+        h.normal = normalize(mat_mul(x->fwd, h.normal));
+        h.t = h.t / nrm;
+    }
+    return h;
+}
+
+// ---- BVH traversal ------------------------------------------------------------------------------
+// Ray::intersects_aabb, ray.rs:167-189 (divisions, running interval, strict tmin < tmax).
+inline bool slab(const float *lo, const float *hi, const Ray &r, float t_min, float t_max, float &entry) {
+    for (int a = 0; a < 3; ++a) {
+        float min_val = (lo[a] - r.o[a]) / r.d[a];
+        float max_val = (hi[a] - r.o[a]) / r.d[a];
+        t_min = std::fmax(std::fmin(min_val, max_val), t_min);
+        t_max = std::fmin(std::fmax(min_val, max_val), t_max);
+        if (!(t_min < t_max)) return false;
+    }
+    entry = t_min;
+    return true;
+}
+
+struct Closest {
+    uint32_t prim = 0xFFFFFFFFu;
+    Hit hit;
+};
+
+// closest-hit rule of ray_color, renderer.rs:149-183: strictly smaller t wins; shapes are visited in
+// ascending index, so equal t keeps the lowest index.
+inline void consider(Ctx &ctx, Closest &c, uint32_t prim_index, const Ray &r) {
+    ctx.cnt.prims++;
+    Hit h = hit_prim(ctx, ctx.s->prims[prim_index], prim_index, r, EPSILON, INF);
+    if (!h.mask) return;
+    if (c.hit.t > h.t || (c.hit.t == h.t && c.hit.mask && prim_index < c.prim)) {
+        c.prim = prim_index;
+        c.hit = h;
+    }
+}
+
+// BVH::traverse, bvh/bvh.rs:182-239: every leaf whose ancestors' boxes the ray enters is a
+// candidate; no near/far ordering, no interval shrinking.
+void traverse_reference(Ctx &ctx, uint32_t node, const Ray &r, Closest &c) {
+    const v4r_bvh_node &n = ctx.s->nodes[node];
+    ctx.cnt.nodes++;
+    float entry;
+    if (slab(n.lo0, n.hi0, r, EPSILON, INF, entry)) {
+        if (n.child0 & V4R_LEAF_BIT) consider(ctx, c, n.child0 & ~V4R_LEAF_BIT, r);
+        else traverse_reference(ctx, n.child0, r, c);
+    }
+    if (slab(n.lo1, n.hi1, r, EPSILON, INF, entry)) {
+        if (n.child1 & V4R_LEAF_BIT) consider(ctx, c, n.child1 & ~V4R_LEAF_BIT, r);
+        else traverse_reference(ctx, n.child1, r, c);
+    }
+}
+
+// The device's traversal order (near child first, far child stacked with its entry distance,
+// subtrees skipped once their entry distance exceeds the closest hit), restated for the work
+// counters; it returns the same closest hit as traverse_reference.
+void traverse_ordered(Ctx &ctx, const Ray &r, Closest &c) {
+    struct Entry {
+        uint32_t node;
+        float entry;
+    };
+    std::vector<Entry> stack;
+    uint32_t node = 0;
+    while (true) {
+        const v4r_bvh_node &n = ctx.s->nodes[node];
+        ctx.cnt.nodes++;
+        float e0 = 0, e1 = 0;
+        bool h0 = slab(n.lo0, n.hi0, r, EPSILON, INF, e0) && e0 <= c.hit.t;
+        bool h1 = slab(n.lo1, n.hi1, r, EPSILON, INF, e1) && e1 <= c.hit.t;
+        if (h0 && (n.child0 & V4R_LEAF_BIT)) {
+            consider(ctx, c, n.child0 & ~V4R_LEAF_BIT, r);
+            h0 = false;
+        }
+        if (h1 && (n.child1 & V4R_LEAF_BIT)) {
+            // the first leaf may have shortened the interval
+            if (e1 <= c.hit.t) consider(ctx, c, n.child1 & ~V4R_LEAF_BIT, r);
+            h1 = false;
+        }
+        if (h0 && h1) {
+            bool first0 = e0 <= e1;
+            stack.push_back(first0 ? Entry{n.child1, e1} : Entry{n.child0, e0});
+            node = first0 ? n.child0 : n.child1;
+            continue;
+        }
+        if (h0 || h1) {
+            node = h0 ? n.child0 : n.child1;
+            float e = h0 ? e0 : e1;
+            if (e <= c.hit.t) continue;
+        }
+        bool found = false;
+        while (!stack.empty()) {
+            Entry e = stack.back();
+            stack.pop_back();
+            if (e.entry <= c.hit.t) {
+                node = e.node;
+                found = true;
+                break;
+            }
+        }
+        if (!found) return;
+    }
+}
+
+Closest trace(Ctx &ctx, const Ray &r, int mode) {
+    Closest c;
+    ctx.cnt.segments++;
+    const v4r_scene_desc *s = ctx.s;
+    if (s->n_prims == 0) return c;
+    if (s->n_nodes == 0) {  // a single shape: the root is a leaf, tested without any box (bvh.rs:218-224)
+        consider(ctx, c, 0, r);
+        return c;
+    }
+    if (mode == 1) traverse_ordered(ctx, r, c);
+    else traverse_reference(ctx, 0, r, c);
+    return c;
+}
+
+// ---- textures -----------------------------------------------------------------------------------
+// Rust `x as isize` for f32: truncate toward zero, saturate, NaN -> 0
+inline int64_t f32_to_isize(float x) {
+    if (!(x == x)) return 0;
+    if (x >= 9.2233720368547758e18f) return INT64_MAX;
+    if (x <= -9.2233720368547758e18f) return INT64_MIN;
+    return (int64_t)x;
+}
+inline uint32_t f32_to_u32(float x) {  // Rust `x as u32`
+    if (!(x == x) || x <= 0.0f) return 0;
+    if (x >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)x;
+}
+
+// Perlin::noise + perlin_interp, texture/noise.rs:41-89,109-140
+float perlin_noise(const v4r_perlin &pt, V3 p) {
+    float fx = std::floor(p.x), fy = std::floor(p.y), fz = std::floor(p.z);
+    float u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    int64_t i = f32_to_isize(fx), j = f32_to_isize(fy), k = f32_to_isize(fz);
+    float uu = u * u * (3.0f - u * 2.0f);
+    float vv = v * v * (3.0f - v * 2.0f);
+    float ww = w * w * (3.0f - w * 2.0f);
+    float accum = 0.0f;
+    for (int di = 0; di < 2; ++di)
+        for (int dj = 0; dj < 2; ++dj)
+            for (int dk = 0; dk < 2; ++dk) {
+                // wrapping add then rem_euclid(256) == low 8 bits of the two's-complement sum
+                uint32_t ix = (uint32_t)((uint64_t)i + (uint64_t)di) & 255u;
+                uint32_t iy = (uint32_t)((uint64_t)j + (uint64_t)dj) & 255u;
+                uint32_t iz = (uint32_t)((uint64_t)k + (uint64_t)dk) & 255u;
+                const float *c = pt.vec[pt.perm_x[ix] ^ pt.perm_y[iy] ^ pt.perm_z[iz]];
+                V3 weight = v3(u - (float)di, v - (float)dj, w - (float)dk);
+                float term = (di ? uu : 1.0f - uu) * (dj ? vv : 1.0f - vv) * (dk ? ww : 1.0f - ww) * dot(v3(c), weight);
+                accum += term;
+            }
+    return accum;
+}
+
+// Perlin::turb, texture/noise.rs:91-107
+float perlin_turb(const v4r_perlin &pt, V3 p, uint32_t depth) {
+    float accum = 0.0f, weight = 1.0f;
+    for (uint32_t d = 0; d < depth; ++d) {
+        accum += weight * perlin_noise(pt, p);
+        weight *= 0.5f;
+        p = p * 2.0f;
+    }
+    return std::fabs(accum);
+}
+
+V3 texture_value(Ctx &ctx, uint32_t tex, float u, float v, V3 p) {
+    const v4r_scene_desc *s = ctx.s;
+    for (int guard = 0; guard < 64; ++guard) {
+        const v4r_texture &t = s->textures[tex];
+        switch (t.kind) {
+            case V4R_TEX_SOLID:  // texture/solid_color.rs:25-27
+                return v3(t.color);
+            case V4R_TEX_CHECKER: {  // texture/checker.rs:31-38 (is_simd_positive is `> 0`)
+                float sines = std::sin(t.s * p.x) * std::sin(t.s * p.y) * std::sin(t.s * p.z);
+                tex = sines > 0.0f ? t.b : t.a;  // even : odd
+                continue;
+            }
+            case V4R_TEX_IMAGE: {  // texture/image.rs:25-73
+                const v4r_image &img = s->images[t.a];
+                float cu = u < 0.0f ? 0.0f : (u > 1.0f ? 1.0f : u);
+                float cv = 1.0f - (v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v));
+                uint32_t i = f32_to_u32((float)img.width * cu);
+                if (!(i < img.width)) i = img.width - 1;
+                uint32_t j = f32_to_u32((float)img.height * cv);
+                if (!(j < img.height)) j = img.height - 1;
+                const uint8_t *px = s->texels + img.offset + ((size_t)j * img.width + i) * 3;
+                ctx.cnt.texels++;
+                return v3((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
+            }
+            case V4R_TEX_NOISE: {  // texture/noise.rs:165-170
+                float g = perlin_turb(s->perlin[t.a], p * t.s, t.b);
+                return v3(g, g, g);
+            }
+            default: return v3(0, 0, 0);
+        }
+    }
+    return v3(0, 0, 0);
+}
+
+// ---- pdfs ---------------------------------------------------------------------------------------
+// Rotation3::face_towards(dir, up) (nalgebra 0.27): columns x = normalize(up x z), y = normalize(z x x'),
+// z = normalize(dir).
+struct Rot {
+    V3 x, y, z;
+    V3 apply(V3 v) const { return x * v.x + y * v.y + z * v.z; }
+};
+inline Rot face_towards(V3 dir, V3 up) {
+    Rot r;
+    r.z = normalize(dir);
+    r.x = normalize(cross(up, r.z));
+    r.y = normalize(cross(r.z, r.x));
+    return r;
+}
+// `up` selection shared by CosinePdf::new (pdf/cosine.rs:16-25) and Sphere::generate (sphere.rs:134-140)
+inline V3 pick_up(float x_component) { return std::fabs(x_component) > 0.9f ? v3(0, 1, 0) : v3(1, 0, 0); }
+
+// Matrix3 * Vector3 as nalgebra evaluates it: column-major accumulation x*col0 + y*col1 + z*col2
+inline V3 rot_apply(const Rot &r, V3 v) { return r.apply(v); }
+
+// CosinePdf::value, pdf/cosine.rs:32-37
+inline float cosine_value(V3 normal, V3 dir) {
+    float c = dot(dir, normal);
+    return c > 0.0f ? c * FRAC_1_PI : 0.0f;
+}
+// CosinePdf::generate, pdf/cosine.rs:38-47
+inline V3 cosine_generate(V3 normal, float r1, float r2) {
+    Rot rot = face_towards(normal, pick_up(normal.x));
+    float z = std::sqrt(1.0f - r2);
+    float phi = TWO_PI * r1;
+    float sq = std::sqrt(r2);
+    float x = std::cos(phi) * sq;
+    float y = std::sin(phi) * sq;
+    return rot_apply(rot, v3(x, y, z));
+}
+
+// random_to_sphere, random.rs:27-39
+inline V3 random_to_sphere(float radius, float distance_squared, float u_phi, float r2) {
+    float phi = TWO_PI * u_phi;
+    float z = 1.0f + r2 * (std::sqrt(1.0f - radius * radius / distance_squared) - 1.0f);
+    float xy = std::sqrt(1.0f - z * z);
+    return v3(std::cos(phi) * xy, std::sin(phi) * xy, z);
+}
+
+// Samplable::value of one light primitive (object space), for direction `dir` from `origin`.
+float light_value_object(Ctx &ctx, const v4r_prim &pr, V3 origin, V3 dir) {
+    Ray r{origin, dir};
+    bool bounded = ctx.s->flags & V4R_FLAG_BOUNDED_LIGHT_PDF;
+    switch (pr.type & V4R_PRIM_TYPE_MASK) {
+        case V4R_PRIM_SPHERE: {  // hittable/sphere.rs:100-131
+            Hit h = hit_sphere(pr.f, r, EPSILON, INF);
+            if (!h.mask) return 0.0f;
+            float radius = pr.f[3];
+            float cos_theta_max = std::sqrt(1.0f - radius * radius / norm2(v3(pr.f) - origin));
+            float solid_angle = TWO_PI * (1.0f - cos_theta_max);
+            return solid_angle > 0.0f ? 1.0f / solid_angle : INF;
+        }
+        case V4R_PRIM_XY_RECT:
+        case V4R_PRIM_YZ_RECT:
+        case V4R_PRIM_ZX_RECT: {  // hittable/aa_rect.rs:151-180
+            Hit h = hit_rect(pr, r, EPSILON, INF, !bounded);
+            if (bounded && !h.mask) return 0.0f;
+            float area = (pr.f[1] - pr.f[0]) * (pr.f[3] - pr.f[2]);
+            float distance_squared = h.t * h.t;
+            float cosine = std::fabs(dot(dir, h.normal));
+            return cosine > 0.0f ? distance_squared / (cosine * area) : INF;
+        }
+        case V4R_PRIM_TRIANGLE: {  // hittable/triangle.rs:103-132
+            Hit h = hit_triangle(pr, ctx.s->tri_shading[pr.aux], r, EPSILON, INF, !bounded);
+            if (bounded && !h.mask) return 0.0f;
+            float area = norm(cross(v3(pr.f + 3), v3(pr.f + 6))) * 0.5f;
+            float distance_squared = h.t * h.t;
+            float cosine = std::fabs(dot(dir, h.normal));
+            return cosine > 0.0f ? distance_squared / (cosine * area) : INF;
+        }
+        default: return 0.0f;  // Samplable default, hittable/mod.rs:186-194
+    }
+}
+
+// Samplable::generate of one light primitive (object space) from `origin`; u0,u1 are the two draws
+// in the order the reference makes them.
+V3 light_generate_object(const v4r_prim &pr, V3 origin, float u0, float u1) {
+    switch (pr.type & V4R_PRIM_TYPE_MASK) {
+        case V4R_PRIM_SPHERE: {  // hittable/sphere.rs:132-144
+            V3 direction = v3(pr.f) - origin;
+            Rot rot = face_towards(direction, pick_up(normalize(direction).x));
+            return normalize(rot_apply(rot, random_to_sphere(pr.f[3], norm2(direction), u0, u1)));
+        }
+        case V4R_PRIM_XY_RECT: {  // rect_random!, aa_rect.rs:55-61: a first, then b
+            float a = pr.f[0] + (pr.f[1] - pr.f[0]) * u0, b = pr.f[2] + (pr.f[3] - pr.f[2]) * u1;
+            return normalize(v3(a, b, pr.f[4]) - origin);
+        }
+        case V4R_PRIM_YZ_RECT: {  // aa_rect.rs:62-68
+            float a = pr.f[0] + (pr.f[1] - pr.f[0]) * u0, b = pr.f[2] + (pr.f[3] - pr.f[2]) * u1;
+            return normalize(v3(pr.f[4], a, b) - origin);
+        }
+        case V4R_PRIM_ZX_RECT: {  // aa_rect.rs:69-75: the x coordinate (b range) is drawn first
+            float b = pr.f[2] + (pr.f[3] - pr.f[2]) * u0, a = pr.f[0] + (pr.f[1] - pr.f[0]) * u1;
+            return normalize(v3(b, pr.f[4], a) - origin);
+        }
+        case V4R_PRIM_TRIANGLE: {  // hittable/triangle.rs:134-146
+            float lo = EPSILON, hi = 1.0f - EPSILON;
+            float x = lo + (hi - lo) * u0, y = lo + (hi - lo) * u1;
+            if (x + y > 1.0f) {
+                x = 1.0f - EPSILON - x;
+                y = 1.0f - EPSILON - y;
+            }
+            V3 point = v3(pr.f) + v3(pr.f + 3) * x + v3(pr.f + 6) * y;
+            return normalize(point - origin);
+        }
+        default: return v3(1, 0, 0);  // hittable/mod.rs:195-197
+    }
+}
+
+// TransformHittable::{value, generate}, hittable/transform.rs:103-124 (no Jacobian, as written there)
+float light_value(Ctx &ctx, uint32_t prim_index, V3 origin, V3 dir) {
+    const v4r_prim &pr = ctx.s->prims[prim_index];
+    if (pr.xform != V4R_NO_XFORM) {
+        const v4r_xform &x = ctx.s->xforms[pr.xform];
+        origin = mat_mul(x.inv, origin) + v3(x.inv_t);
+        dir = normalize(mat_mul(x.inv, dir));
+    }
+    return light_value_object(ctx, pr, origin, dir);
+}
+V3 light_generate(Ctx &ctx, uint32_t prim_index, V3 origin, float u0, float u1) {
+    const v4r_prim &pr = ctx.s->prims[prim_index];
+    if (pr.xform != V4R_NO_XFORM) {
+        const v4r_xform &x = ctx.s->xforms[pr.xform];
+        origin = mat_mul(x.inv, origin) + v3(x.inv_t);
+        return normalize(mat_mul(x.fwd, light_generate_object(pr, origin, u0, u1)));
+    }
+    return light_generate_object(pr, origin, u0, u1);
+}
+
+// HittableGroup::value over the light list, hittables/group.rs:76-89
+float lights_value(Ctx &ctx, V3 origin, V3 dir) {
+    uint32_t n = ctx.s->n_lights;
+    float weight = 1.0f / (float)n;
+    float sum = 0.0f;
+    for (uint32_t i = 0; i < n; ++i) sum += weight * light_value(ctx, ctx.s->lights[i], origin, dir);
+    return sum;
+}
+
+// ---- materials ----------------------------------------------------------------------------------
+inline V3 reflect(V3 v, V3 n) { return v - n * (dot(v, n) * 2.0f); }  // material/mod.rs:47-52
+inline V3 refract(V3 uv, V3 n, float etai_over_etat) {               // material/mod.rs:54-63
+    float cos_theta = -dot(uv, n);
+    V3 r_out_perp = (uv + n * cos_theta) * etai_over_etat;
+    V3 r_out_parallel = n * (-std::sqrt(1.0f - norm2(r_out_perp)));
+    return r_out_perp + r_out_parallel;
+}
+inline float reflectance(float cosine, float ref_idx) {  // material/dielectric.rs:23-27
+    float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
+    r0 = r0 * r0;
+    float x = 1.0f - cosine;
+    float x2 = x * x;
+    return r0 + (1.0f - r0) * (x2 * x2 * x);
+}
+
+struct Scatter {
+    bool scattered = false;  // false = ScatterRecord::None
+    V3 coef{0, 0, 0};
+    V3 dir{0, 0, 0};
+    V3 emitted{0, 0, 0};
+};
+
+// Material::emitted + Material::scatter + the pdf branch of ray_color (renderer.rs:218-263)
+Scatter shade(Ctx &ctx, uint32_t prim_index, const Ray &ray, const Hit &h) {
+    const v4r_scene_desc *s = ctx.s;
+    const v4r_material &m = s->materials[s->prim_material[prim_index]];
+    uint32_t key = ctx.seg_key;
+    Scatter out;
+    ctx.cnt.shaded++;
+    switch (m.kind) {
+        case V4R_MAT_DIFFUSE_LIGHT: {  // material/diffuse_light.rs:19-22; scatter is the default None
+            V3 c = texture_value(ctx, m.tex, h.u, h.v, h.p);
+            out.emitted = h.front_face ? c : v3(0, 0, 0);
+            return out;
+        }
+        case V4R_MAT_LAMBERTIAN: {  // material/lambertian.rs:36-46
+            V3 attenuation = texture_value(ctx, m.tex, h.u, h.v, h.p);
+            out.scattered = true;
+            if (s->n_lights != 0) {  // renderer.rs:234-244
+                // MixturePdf::generate, pdf/mixture.rs:27-32: both members generate, then select
+                bool pick_light = draw(key, DIM_SCATTER + 0) < 0.5f;
+                // HittableGroup::generate, hittables/group.rs:91-95
+                uint32_t n = s->n_lights;
+                uint32_t li = (uint32_t)(((uint64_t)draw_u32(key, DIM_SCATTER + 1) * n) >> 32);
+                V3 d_light = light_generate(ctx, s->lights[li], h.p, draw(key, DIM_SCATTER + 2), draw(key, DIM_SCATTER + 3));
+                V3 d_cos = cosine_generate(h.normal, draw(key, DIM_SCATTER + 4), draw(key, DIM_SCATTER + 5));
+                V3 dir = pick_light ? d_light : d_cos;
+                float pdf_v = cosine_value(h.normal, dir);
+                float mix_v = 0.5f * lights_value(ctx, h.p, dir) + 0.5f * pdf_v;  // pdf/mixture.rs:22-25
+                out.coef = attenuation * pdf_v / mix_v;
+                out.dir = dir;
+            } else {  // renderer.rs:245-255
+                out.dir = cosine_generate(h.normal, draw(key, DIM_SCATTER + 4), draw(key, DIM_SCATTER + 5));
+                out.coef = attenuation;
+            }
+            return out;
+        }
+        case V4R_MAT_METAL: {  // material/metal.rs:31-46, random_in_unit_sphere random.rs:53-65
+            V3 reflected = reflect(ray.d, h.normal);
+            float theta = TWO_PI * draw(key, DIM_SCATTER + 0);
+            float cos_phi = -1.0f + 2.0f * draw(key, DIM_SCATTER + 1);
+            float r = std::pow(draw(key, DIM_SCATTER + 2), 1.0f / 3.0f);
+            float sin_phi = std::sqrt(1.0f - cos_phi * cos_phi);
+            V3 ball = v3(r * sin_phi * std::cos(theta), r * sin_phi * std::sin(theta), r * cos_phi);
+            out.scattered = true;
+            out.dir = normalize(reflected + ball * m.fuzz);
+            out.coef = v3(m.albedo);
+            return out;
+        }
+        case V4R_MAT_DIELECTRIC: {  // material/dielectric.rs:33-60
+            float ratio = h.front_face ? 1.0f / m.ir : m.ir;
+            float cos_theta = -dot(ray.d, h.normal);
+            float sin_theta = std::sqrt(1.0f - cos_theta * cos_theta);
+            bool cannot_refract = ratio * sin_theta > 1.0f;
+            cannot_refract = cannot_refract || reflectance(cos_theta, ratio) > draw(key, DIM_SCATTER + 0);
+            out.scattered = true;
+            out.dir = cannot_refract ? reflect(ray.d, h.normal) : refract(ray.d, h.normal, ratio);
+            out.coef = v3(1, 1, 1);
+            return out;
+        }
+        case V4R_MAT_ISOTROPIC: {  // material/isotropic.rs:26-43, random_on_unit_sphere random.rs:41-51
+            float z = -1.0f + 2.0f * draw(key, DIM_SCATTER + 0);
+            float theta = TWO_PI * draw(key, DIM_SCATTER + 1);
+            float xy = std::sqrt(1.0f - z * z);
+            out.scattered = true;
+            out.dir = v3(std::cos(theta) * xy, std::sin(theta) * xy, z);
+            out.coef = texture_value(ctx, m.tex, h.u, h.v, h.p);
+            return out;
+        }
+        default: return out;
+    }
+}
+
+// ---- camera -------------------------------------------------------------------------------------
+// Renderer::sample (renderer.rs:94-122) + Camera::get_ray (camera.rs:113-129) for pixel (row, col),
+// row 0 = top of the image.
+Ray camera_ray(const v4r_scene_desc *s, uint32_t row, uint32_t col, uint32_t key, bool deterministic) {
+    const v4r_camera &c = s->camera;
+    float width = (float)s->width, height = (float)s->height;
+    float i = (float)col, j = (float)(s->height - 1 - row);
+    float sx, sy;
+    if (deterministic || !s->antialias) {
+        sx = i / width;
+        sy = j / height;
+    } else {
+        sx = draw_range(key, DIM_PIXEL_X, (i - 0.5f) / width, (i + 0.5f) / width);
+        sy = draw_range(key, DIM_PIXEL_Y, (j - 0.5f) / height, (j + 0.5f) / height);
+    }
+    V3 offset = v3(0, 0, 0);
+    if (!deterministic) {
+        // random_in_unit_disk, random.rs:18-25
+        float r = std::sqrt(draw(key, DIM_LENS_R));
+        float theta = TWO_PI * draw(key, DIM_LENS_THETA);
+        float rdx = r * std::cos(theta) * c.lens_radius, rdy = r * std::sin(theta) * c.lens_radius;
+        offset = v3(c.u) * rdx + v3(c.v) * rdy;
+    }
+    V3 source = v3(c.origin) + offset;
+    V3 target = v3(c.lower_left_corner) + v3(c.horizontal) * sx + v3(c.vertical) * sy;
+    return Ray{source, normalize(target - source)};
+}
+
+// One camera path: the per-path unrolling of ray_color (renderer.rs:123-320).
+V3 path_radiance(Ctx &ctx, uint64_t seed, uint32_t pass, uint32_t pixel, int mode) {
+    const v4r_scene_desc *s = ctx.s;
+    PathKey pk = path_key(seed, pass, pixel);
+    ctx.cnt.paths++;
+    ctx.seg_key = segment_key(pk, 0);
+    Ray ray = camera_ray(s, pixel / s->width, pixel % s->width, ctx.seg_key, false);
+    V3 thr = v3(1, 1, 1);
+    for (uint32_t seg = 0; seg < s->max_depth; ++seg) {
+        ctx.seg_key = segment_key(pk, seg);
+        Closest c = trace(ctx, ray, mode);
+        if (!c.hit.mask) return thr * v3(s->background);  // renderer.rs:184
+        Scatter sc = shade(ctx, c.prim, ray, c.hit);
+        if (!sc.scattered) return thr * sc.emitted;  // renderer.rs:218-230,261
+        thr = thr * sc.coef;                         // renderer.rs:299-318
+        ray = Ray{c.hit.p, sc.dir};
+    }
+    return thr * v3(s->environment);  // renderer.rs:128-130
+}
+
+int validate(const v4r_scene_desc *s) {
+    if (!s) {
+        g_error = "NULL scene";
+        return V4R_E_INVALID;
+    }
+    if (s->abi_version != V4R_ABI_VERSION) {
+        g_error = "ABI version mismatch";
+        return V4R_E_INVALID;
+    }
+    if (s->width == 0 || s->height == 0) {
+        g_error = "empty image";
+        return V4R_E_INVALID;
+    }
+    return V4R_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *v4o_last_error(void) { return g_error.c_str(); }
+
+// Adds n_passes full-image passes into accum (H*W*3 floats, row 0 = top).  mode 0 = the
+// reference's candidate-set traversal, 1 = the device's ordered traversal.  pixel_stride > 1
+// renders only pixels whose index is a multiple of it (for strided work counts).
+int v4o_render(const v4r_scene_desc *s, uint64_t seed, uint32_t first_pass, uint32_t pass_stride, uint32_t n_passes,
+               float *accum, int n_threads, uint32_t pixel_stride, int mode, v4r_stats *stats) {
+    if (int rc = validate(s)) return rc;
+    if (!accum) {
+        g_error = "NULL accumulator";
+        return V4R_E_INVALID;
+    }
+    if (pixel_stride == 0) pixel_stride = 1;
+    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    if (n_threads <= 0) n_threads = 1;
+    uint32_t npix = s->width * s->height;
+    // main.rs:56-63 runs whole passes concurrently; here the image is split into chunks handed out
+    // dynamically, and each pixel's passes are summed in ascending pass order (deterministic).
+    std::atomic<uint32_t> next{0};
+    const uint32_t chunk = 256;
+    std::vector<Counters> counters((size_t)n_threads);
+    auto worker = [&](int tid) {
+        Ctx ctx{s};
+        while (true) {
+            uint32_t begin = next.fetch_add(chunk);
+            if (begin >= npix) break;
+            uint32_t end = begin + chunk < npix ? begin + chunk : npix;
+            for (uint32_t pix = begin; pix < end; ++pix) {
+                if (pix % pixel_stride) continue;
+                for (uint32_t k = 0; k < n_passes; ++k) {
+                    V3 c = path_radiance(ctx, seed, first_pass + k * pass_stride, pix, mode);
+                    accum[3 * (size_t)pix] += c.x;
+                    accum[3 * (size_t)pix + 1] += c.y;
+                    accum[3 * (size_t)pix + 2] += c.z;
+                }
+            }
+        }
+        counters[(size_t)tid] = ctx.cnt;
+    };
+    std::vector<std::thread> threads;
+    for (int t = 1; t < n_threads; ++t) threads.emplace_back(worker, t);
+    worker(0);
+    for (auto &t : threads) t.join();
+    if (stats) {
+        Counters total;
+        for (auto &c : counters) total.add(c);
+        stats->segments = total.segments;
+        stats->nodes = total.nodes;
+        stats->prims = total.prims;
+        stats->paths = total.paths;
+        stats->shaded = total.shaded;
+        stats->texel_fetches = total.texels;
+    }
+    return V4R_OK;
+}
+
+// Deterministic primary rays (pixel centres, no lens sample): closest primitive and t per pixel.
+int v4o_trace_primary(const v4r_scene_desc *s, uint32_t *prim_id, float *t, int mode) {
+    if (int rc = validate(s)) return rc;
+    Ctx ctx{s};
+    uint32_t npix = s->width * s->height;
+    for (uint32_t pix = 0; pix < npix; ++pix) {
+        Ray r = camera_ray(s, pix / s->width, pix % s->width, 0, true);
+        ctx.seg_key = 0;
+        Closest c = trace(ctx, r, mode);
+        if (prim_id) prim_id[pix] = c.prim;
+        if (t) t[pix] = c.hit.t;
+    }
+    return V4R_OK;
+}
+
+// Camera rays exactly as the device generates them for pass `pass` (origin, direction per pixel).
+int v4o_camera_rays(const v4r_scene_desc *s, uint64_t seed, uint32_t pass, int deterministic, float *origin, float *dir) {
+    if (int rc = validate(s)) return rc;
+    uint32_t npix = s->width * s->height;
+    for (uint32_t pix = 0; pix < npix; ++pix) {
+        uint32_t key = segment_key(path_key(seed, pass, pix), 0);
+        Ray r = camera_ray(s, pix / s->width, pix % s->width, key, deterministic != 0);
+        if (origin) {
+            origin[3 * pix] = r.o.x;
+            origin[3 * pix + 1] = r.o.y;
+            origin[3 * pix + 2] = r.o.z;
+        }
+        if (dir) {
+            dir[3 * pix] = r.d.x;
+            dir[3 * pix + 1] = r.d.y;
+            dir[3 * pix + 2] = r.d.z;
+        }
+    }
+    return V4R_OK;
+}
+
+// Closest hit of caller-supplied rays. rec (optional) receives 10 floats per ray:
+// p.xyz, normal.xyz, u, v, front_face, hit mask.  Ray i uses segment key mix32(seed_lo + i) for media.
+int v4o_trace_rays(const v4r_scene_desc *s, uint32_t n, const float *origin, const float *dir, uint64_t seed,
+                   uint32_t *prim_id, float *t, float *rec, int mode) {
+    if (int rc = validate(s)) return rc;
+    Ctx ctx{s};
+    for (uint32_t i = 0; i < n; ++i) {
+        Ray r{v3(origin + 3 * i), v3(dir + 3 * i)};
+        ctx.seg_key = segment_key(path_key(seed, 0, i), 0);
+        Closest c = trace(ctx, r, mode);
+        if (prim_id) prim_id[i] = c.prim;
+        if (t) t[i] = c.hit.t;
+        if (rec) {
+            float *o = rec + 10 * (size_t)i;
+            o[0] = c.hit.p.x; o[1] = c.hit.p.y; o[2] = c.hit.p.z;
+            o[3] = c.hit.normal.x; o[4] = c.hit.normal.y; o[5] = c.hit.normal.z;
+            o[6] = c.hit.u; o[7] = c.hit.v;
+            o[8] = c.hit.front_face ? 1.0f : 0.0f;
+            o[9] = c.hit.mask ? 1.0f : 0.0f;
+        }
+    }
+    return V4R_OK;
+}
+
+// Hittable::hit of primitive `prim_index` alone (no BVH) with an explicit interval.
+int v4o_hit(const v4r_scene_desc *s, uint32_t prim_index, const float origin[3], const float dir[3], float t_min,
+            float t_max, uint32_t seg_key, float rec[11]) {
+    if (int rc = validate(s)) return rc;
+    if (prim_index >= s->n_prims) {
+        g_error = "primitive index out of range";
+        return V4R_E_INVALID;
+    }
+    Ctx ctx{s};
+    ctx.seg_key = seg_key;
+    Hit h = hit_prim(ctx, s->prims[prim_index], prim_index, Ray{v3(origin), v3(dir)}, t_min, t_max);
+    rec[0] = h.p.x; rec[1] = h.p.y; rec[2] = h.p.z;
+    rec[3] = h.normal.x; rec[4] = h.normal.y; rec[5] = h.normal.z;
+    rec[6] = h.t; rec[7] = h.u; rec[8] = h.v;
+    rec[9] = h.front_face ? 1.0f : 0.0f;
+    rec[10] = h.mask ? 1.0f : 0.0f;
+    return V4R_OK;
+}
+
+int v4o_slab(const float lo[3], const float hi[3], const float origin[3], const float dir[3], float t_min, float t_max) {
+    float e;
+    return slab(lo, hi, Ray{v3(origin), v3(dir)}, t_min, t_max, e) ? 1 : 0;
+}
+
+int v4o_texture_value(const v4r_scene_desc *s, uint32_t tex, float u, float v, const float p[3], float rgb[3]) {
+    if (int rc = validate(s)) return rc;
+    if (tex >= s->n_textures) {
+        g_error = "texture index out of range";
+        return V4R_E_INVALID;
+    }
+    Ctx ctx{s};
+    V3 c = texture_value(ctx, tex, u, v, v3(p));
+    rgb[0] = c.x; rgb[1] = c.y; rgb[2] = c.z;
+    return V4R_OK;
+}
+
+// Shade one hit: rec = the 11 floats v4o_hit returns.  out: scattered flag, coef.rgb, dir.xyz, emitted.rgb
+int v4o_shade(const v4r_scene_desc *s, uint32_t prim_index, const float origin[3], const float dir[3], const float rec[11],
+              uint32_t seg_key, float out[10]) {
+    if (int rc = validate(s)) return rc;
+    if (prim_index >= s->n_prims) {
+        g_error = "primitive index out of range";
+        return V4R_E_INVALID;
+    }
+    Ctx ctx{s};
+    ctx.seg_key = seg_key;
+    Hit h;
+    h.p = v3(rec); h.normal = v3(rec + 3); h.t = rec[6]; h.u = rec[7]; h.v = rec[8];
+    h.front_face = rec[9] != 0.0f; h.mask = rec[10] != 0.0f;
+    Scatter sc = shade(ctx, prim_index, Ray{v3(origin), v3(dir)}, h);
+    out[0] = sc.scattered ? 1.0f : 0.0f;
+    out[1] = sc.coef.x; out[2] = sc.coef.y; out[3] = sc.coef.z;
+    out[4] = sc.dir.x; out[5] = sc.dir.y; out[6] = sc.dir.z;
+    out[7] = sc.emitted.x; out[8] = sc.emitted.y; out[9] = sc.emitted.z;
+    return V4R_OK;
+}
+
+float v4o_cosine_value(const float normal[3], const float dir[3]) { return cosine_value(v3(normal), v3(dir)); }
+void v4o_cosine_generate(const float normal[3], float r1, float r2, float out[3]) {
+    V3 d = cosine_generate(v3(normal), r1, r2);
+    out[0] = d.x; out[1] = d.y; out[2] = d.z;
+}
+void v4o_onb(const float normal[3], float out9[9]) {  // columns x, y, z of the CosinePdf rotation
+    Rot r = face_towards(v3(normal), pick_up(normal[0]));
+    out9[0] = r.x.x; out9[1] = r.x.y; out9[2] = r.x.z;
+    out9[3] = r.y.x; out9[4] = r.y.y; out9[5] = r.y.z;
+    out9[6] = r.z.x; out9[7] = r.z.y; out9[8] = r.z.z;
+}
+int v4o_light_value(const v4r_scene_desc *s, uint32_t prim_index, const float origin[3], const float dir[3], float *out) {
+    if (int rc = validate(s)) return rc;
+    Ctx ctx{s};
+    *out = light_value(ctx, prim_index, v3(origin), v3(dir));
+    return V4R_OK;
+}
+int v4o_light_generate(const v4r_scene_desc *s, uint32_t prim_index, const float origin[3], float u0, float u1, float out[3]) {
+    if (int rc = validate(s)) return rc;
+    Ctx ctx{s};
+    V3 d = light_generate(ctx, prim_index, v3(origin), u0, u1);
+    out[0] = d.x; out[1] = d.y; out[2] = d.z;
+    return V4R_OK;
+}
+void v4o_reflect(const float v[3], const float n[3], float out[3]) {
+    V3 r = reflect(v3(v), v3(n));
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+void v4o_refract(const float v[3], const float n[3], float ratio, float out[3]) {
+    V3 r = refract(v3(v), v3(n), ratio);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+float v4o_reflectance(float cosine, float ref_idx) { return reflectance(cosine, ref_idx); }
+
+// the random-number definition, exposed so tests can pin device and oracle to the same streams
+uint32_t v4o_rng_segment_key(uint64_t seed, uint32_t pass, uint32_t pixel, uint32_t segment) {
+    return segment_key(path_key(seed, pass, pixel), segment);
+}
+float v4o_rng_draw(uint32_t seg_key, uint32_t dim) { return draw(seg_key, dim); }
+
+}  // extern "C"

@@ -1,0 +1,907 @@
+// gfx950 wavefront path tracer: kernels and the C ABI of include/v4ray_hip.h.
+//
+// One batch = `P` full-image passes = P*W*H camera paths.  Per batch:
+//   k_raygen                       camera rays -> ray queue 0                (renderer.rs:94-122, camera.rs:113-129)
+//   for segment s = 0 .. max_depth-1:
+//     k_trace(s)                   BVH traversal + closest hit; misses write background;
+//                                  hits are binned by material class into hit queues (wave64
+//                                  ballot + prefix rank, one atomic per wave and class)
+//     k_shade<class>(s)            per-class material evaluation -> next ray queue
+//   k_resolve                      per-pixel sum of the batch's path radiances into the accumulator
+//
+// Queue records are 16-byte columns (structure of float4 arrays), so every queue access of a wave
+// is one contiguous 1 KiB transaction per column.  A path's radiance is written exactly once,
+// when it terminates (miss, light, depth exhausted), into a per-path slot; k_resolve adds the
+// slots of a pixel in ascending pass order, which keeps the image bit-reproducible.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "v4r_scene_dev.hpp"
+#include "v4ray_hip.h"
+
+using namespace v4r;
+
+namespace {
+
+constexpr int BLOCK = 256;
+
+// Per-segment queue counters, zeroed once per batch.
+struct SegCtr {
+    uint32_t ray_count;     // rays queued for k_trace of this segment
+    uint32_t trace_cursor;  // next ray index a wave of k_trace takes
+    uint32_t hit_count[CLS_COUNT];
+    uint32_t shade_cursor[CLS_COUNT];
+    uint32_t pad[2];
+};
+static_assert(sizeof(SegCtr) == 64, "SegCtr is one 64-byte line");
+
+struct Queues {
+    float4 *ray[2][3];          // [segment parity][column]: {o.xyz,d.x} {d.yz,thr.rg} {thr.b,slot,k0,k1}
+    float4 *hit[CLS_COUNT][4];  // the three ray columns + {t, prim, u, v}
+    float4 *rad;                // per path slot: radiance of the finished path
+    SegCtr *ctr;                // [max_depth + 1]
+    uint2 *spill;               // traversal stack overflow, [entry][global thread]
+    unsigned long long *stats;  // segments, nodes, prims, paths, shaded, texel fetches
+    uint32_t spill_stride;
+    uint32_t cap;               // path slots per batch
+};
+
+V4R_DEV uint32_t lane_id() { return threadIdx.x & 63u; }
+
+// Take the next 64 queue entries for this wave.
+V4R_DEV uint32_t wave_fetch(uint32_t *cursor) {
+    uint32_t base = 0;
+    if (lane_id() == 0) base = atomicAdd(cursor, 64u);
+    return __builtin_amdgcn_readfirstlane(base);
+}
+
+// Reserve one output slot per lane with `flag` set: wave ballot, one atomic per wave, prefix rank.
+V4R_DEV uint32_t wave_push(bool flag, uint32_t *counter) {
+    unsigned long long mask = __ballot(flag);
+    if (mask == 0ull) return 0;
+    uint32_t base = 0;
+    if (lane_id() == 0) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __builtin_amdgcn_readfirstlane(base);
+    uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    return base + rank;
+}
+
+V4R_DEV unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+struct PathState {
+    V3 o, d, thr;
+    uint32_t slot, k0, k1;
+};
+
+V4R_DEV void store_ray(float4 *const col[3], uint32_t i, const PathState &p) {
+    col[0][i] = make_float4(p.o.x, p.o.y, p.o.z, p.d.x);
+    col[1][i] = make_float4(p.d.y, p.d.z, p.thr.x, p.thr.y);
+    col[2][i] = make_float4(p.thr.z, __uint_as_float(p.slot), __uint_as_float(p.k0), __uint_as_float(p.k1));
+}
+V4R_DEV PathState unpack_ray(float4 a, float4 b, float4 c) {
+    PathState p;
+    p.o = v3(a.x, a.y, a.z);
+    p.d = v3(a.w, b.x, b.y);
+    p.thr = v3(b.z, b.w, c.x);
+    p.slot = __float_as_uint(c.y);
+    p.k0 = __float_as_uint(c.z);
+    p.k1 = __float_as_uint(c.w);
+    return p;
+}
+
+// Renderer::sample (renderer.rs:94-122) + Camera::get_ray (camera.rs:113-129) for one pixel;
+// row 0 is the top of the image (renderer.rs:101 iterates j from height-1 down).
+V4R_DEV void camera_ray(const SceneDev &S, uint32_t pixel, uint32_t key, bool deterministic, V3 &o, V3 &d) {
+    uint32_t row = pixel / S.width, col = pixel - row * S.width;
+    float width = (float)S.width, height = (float)S.height;
+    float i = (float)col, j = (float)(S.height - 1u - row);
+    float sx, sy;
+    if (deterministic || !S.antialias) {
+        sx = i / width;
+        sy = j / height;
+    } else {
+        float lo = (i - 0.5f) / width, hi = (i + 0.5f) / width;
+        sx = lo + (hi - lo) * draw(key, DIM_PIXEL_X);
+        lo = (j - 0.5f) / height;
+        hi = (j + 0.5f) / height;
+        sy = lo + (hi - lo) * draw(key, DIM_PIXEL_Y);
+    }
+    const v4r_camera &c = S.cam;
+    V3 offset = v3(0, 0, 0);
+    if (!deterministic) {  // random_in_unit_disk, random.rs:18-25
+        float r = sqrtf(draw(key, DIM_LENS_R));
+        float theta = TWO_PI * draw(key, DIM_LENS_THETA);
+        float sn, cs;
+        sincosf(theta, &sn, &cs);
+        float rdx = r * cs * c.lens_radius, rdy = r * sn * c.lens_radius;
+        offset = v3(c.u[0], c.u[1], c.u[2]) * rdx + v3(c.v[0], c.v[1], c.v[2]) * rdy;
+    }
+    V3 source = v3(c.origin[0], c.origin[1], c.origin[2]) + offset;
+    V3 target = v3(c.lower_left_corner[0], c.lower_left_corner[1], c.lower_left_corner[2]) +
+                v3(c.horizontal[0], c.horizontal[1], c.horizontal[2]) * sx + v3(c.vertical[0], c.vertical[1], c.vertical[2]) * sy;
+    o = source;
+    d = normalize(target - source);
+}
+
+// ---- kernels ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_raygen(SceneDev S, Queues Q, uint32_t seed_lo, uint32_t seed_hi,
+                                                  uint32_t first_pass, uint32_t pass_stride, uint32_t n_paths) {
+    uint32_t npix = S.width * S.height;
+    uint32_t stride = gridDim.x * BLOCK;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n_paths; i += stride) {
+        uint32_t b = i / npix, pixel = i - b * npix;
+        PathState p;
+        path_key(seed_lo, seed_hi, first_pass + b * pass_stride, pixel, p.k0, p.k1);
+        camera_ray(S, pixel, segment_key(p.k0, p.k1, 0), false, p.o, p.d);
+        p.thr = v3(1, 1, 1);
+        p.slot = i;
+        store_ray(Q.ray[0], i, p);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        Q.ctr[0].ray_count = n_paths;
+        if (Q.stats) atomicAdd(&Q.stats[3], (unsigned long long)n_paths);
+    }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_trace(SceneDev S, Queues Q, uint32_t seg) {
+    __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
+    Stack st;
+    st.lds = lds_stack + threadIdx.x;
+    st.stride = BLOCK;
+    st.spill = Q.spill + (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    st.spill_stride = Q.spill_stride;
+    st.sp = 0;
+    SegCtr *ctr = Q.ctr + seg;
+    const uint32_t n_in = ctr->ray_count;
+    float4 *const *rq = Q.ray[seg & 1u];
+    TraceCounters cnt;
+    uint32_t n_traced = 0;
+    while (true) {
+        uint32_t base = wave_fetch(&ctr->trace_cursor);
+        if (base >= n_in) break;
+        uint32_t i = base + lane_id();
+        bool valid = i < n_in;
+        uint32_t ii = valid ? i : n_in - 1u;
+        float4 a = rq[0][ii], b = rq[1][ii], c = rq[2][ii];
+        PathState p = unpack_ray(a, b, c);
+        Best best;
+        best.t = V4R_INF;
+        best.prim = NO_PRIM;
+        best.u = best.v = 0.0f;
+        if (valid) {
+            traverse<COUNT>(S, p.o, p.d, st, best, cnt);
+            n_traced++;
+        }
+        bool hit = valid && best.prim != NO_PRIM;
+        if (valid && !hit)  // renderer.rs:184: a miss takes the background colour
+            Q.rad[p.slot] = make_float4(p.thr.x * S.bg[0], p.thr.y * S.bg[1], p.thr.z * S.bg[2], 0.0f);
+        uint32_t cls = hit ? (S.prim_info[best.prim] >> 24) : 0xFFu;
+        float4 dcol = make_float4(best.t, __uint_as_float(best.prim), best.u, best.v);
+#pragma unroll
+        for (uint32_t k = 0; k < CLS_COUNT; ++k) {
+            bool mine = hit && cls == k;
+            uint32_t idx = wave_push(mine, &ctr->hit_count[k]);
+            if (mine) {
+                Q.hit[k][0][idx] = a;
+                Q.hit[k][1][idx] = b;
+                Q.hit[k][2][idx] = c;
+                Q.hit[k][3][idx] = dcol;
+            }
+        }
+    }
+    if (COUNT) {
+        unsigned long long s = wave_sum(n_traced), n = wave_sum(cnt.nodes), q = wave_sum(cnt.prims);
+        if (lane_id() == 0) {
+            atomicAdd(&Q.stats[0], s);
+            atomicAdd(&Q.stats[1], n);
+            atomicAdd(&Q.stats[2], q);
+        }
+    }
+}
+
+// Material::emitted + Material::scatter + the pdf branch of ray_color (renderer.rs:218-263) for one
+// material class, then `colors += coef * child` carried forward as the path throughput
+// (renderer.rs:299-318).
+template <int CLS, bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, Queues Q, uint32_t seg) {
+    SegCtr *ctr = Q.ctr + seg;
+    const uint32_t n_in = ctr->hit_count[CLS];
+    float4 *const *hq = Q.hit[CLS];
+    float4 *const *out = Q.ray[(seg + 1u) & 1u];
+    const bool last = seg + 1u >= S.max_depth;
+    uint32_t n_shaded = 0, texel_fetches = 0;
+    while (true) {
+        uint32_t base = wave_fetch(&ctr->shade_cursor[CLS]);
+        if (base >= n_in) break;
+        uint32_t i = base + lane_id();
+        bool valid = i < n_in;
+        uint32_t ii = valid ? i : n_in - 1u;
+        PathState p = unpack_ray(hq[0][ii], hq[1][ii], hq[2][ii]);
+        float4 dcol = hq[3][ii];
+        float t = dcol.x;
+        uint32_t prim = __float_as_uint(dcol.y);
+        const uint32_t *m = S.materials + 8 * (size_t)(S.prim_info[prim] & 0xFFFFFFu);
+        uint32_t key = segment_key(p.k0, p.k1, seg);
+        if (valid) n_shaded++;
+
+        if (CLS == CLS_LIGHT) {  // material/diffuse_light.rs:19-22; scatter() is the default None
+            HitD h = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, false);
+            V3 e = texture_value(
+                S, m[1], h.p,
+                [&](float &u, float &v) {
+                    HitD hu = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, true);
+                    u = hu.u;
+                    v = hu.v;
+                },
+                texel_fetches);
+            if (!h.front) e = v3(0, 0, 0);
+            if (valid) Q.rad[p.slot] = make_float4(p.thr.x * e.x, p.thr.y * e.y, p.thr.z * e.z, 0.0f);
+            continue;
+        }
+
+        V3 coef, dir;
+        HitD h;
+        if (CLS == CLS_LAMBERT || CLS == CLS_LAMBERT_NOISE) {  // material/lambertian.rs:36-46
+            h = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, false);
+            V3 attenuation = texture_value(
+                S, m[1], h.p,
+                [&](float &u, float &v) {
+                    HitD hu = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, true);
+                    u = hu.u;
+                    v = hu.v;
+                },
+                texel_fetches);
+            V3 d_cos = cosine_generate(h.normal, draw(key, DIM_SCATTER + 4), draw(key, DIM_SCATTER + 5));
+            if (S.n_lights != 0) {  // renderer.rs:234-244, pdf/mixture.rs:22-32, hittables/group.rs:91-95
+                bool pick_light = draw(key, DIM_SCATTER + 0) < 0.5f;
+                uint32_t li = (uint32_t)(((unsigned long long)draw_u32(key, DIM_SCATTER + 1) * S.n_lights) >> 32);
+                V3 d_light = light_generate(S, S.lights[li], h.p, draw(key, DIM_SCATTER + 2), draw(key, DIM_SCATTER + 3));
+                dir = pick_light ? d_light : d_cos;
+                float pdf_v = cosine_value(h.normal, dir);
+                float mix_v = 0.5f * lights_value(S, h.p, dir) + 0.5f * pdf_v;
+                coef = attenuation * pdf_v / mix_v;
+            } else {  // renderer.rs:245-255
+                dir = d_cos;
+                coef = attenuation;
+            }
+        } else if (CLS == CLS_METAL) {  // material/metal.rs:31-46, random_in_unit_sphere random.rs:53-65
+            h = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, false);
+            V3 reflected = reflect(p.d, h.normal);
+            float fuzz = __uint_as_float(m[5]);
+            V3 ball = v3(0, 0, 0);
+            if (fuzz != 0.0f) {
+                float theta = TWO_PI * draw(key, DIM_SCATTER + 0);
+                float cos_phi = -1.0f + 2.0f * draw(key, DIM_SCATTER + 1);
+                float r = powf(draw(key, DIM_SCATTER + 2), 1.0f / 3.0f);
+                float sin_phi = sqrtf(1.0f - cos_phi * cos_phi);
+                float sn, cs;
+                sincosf(theta, &sn, &cs);
+                ball = v3(r * sin_phi * cs, r * sin_phi * sn, r * cos_phi);
+            }
+            dir = normalize(reflected + ball * fuzz);
+            coef = v3(__uint_as_float(m[2]), __uint_as_float(m[3]), __uint_as_float(m[4]));
+        } else if (CLS == CLS_DIELECTRIC) {  // material/dielectric.rs:33-60
+            h = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, false);
+            float ir = __uint_as_float(m[6]);
+            float ratio = h.front ? 1.0f / ir : ir;
+            float cos_theta = -dot(p.d, h.normal);
+            float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+            bool cannot_refract = ratio * sin_theta > 1.0f;
+            cannot_refract = cannot_refract || reflectance(cos_theta, ratio) > draw(key, DIM_SCATTER + 0);
+            dir = cannot_refract ? reflect(p.d, h.normal) : refract(p.d, h.normal, ratio);
+            coef = v3(1, 1, 1);
+        } else {  // CLS_ISOTROPIC: material/isotropic.rs:26-43, random_on_unit_sphere random.rs:41-51
+            h = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, false);
+            float z = -1.0f + 2.0f * draw(key, DIM_SCATTER + 0);
+            float theta = TWO_PI * draw(key, DIM_SCATTER + 1);
+            float xy = sqrtf(1.0f - z * z);
+            float sn, cs;
+            sincosf(theta, &sn, &cs);
+            dir = v3(cs * xy, sn * xy, z);
+            coef = texture_value(
+                S, m[1], h.p,
+                [&](float &u, float &v) {
+                    HitD hu = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, true);
+                    u = hu.u;
+                    v = hu.v;
+                },
+                texel_fetches);
+        }
+        PathState q;
+        q.o = h.p;
+        q.d = dir;
+        q.thr = p.thr * coef;
+        q.slot = p.slot;
+        q.k0 = p.k0;
+        q.k1 = p.k1;
+        if (last) {  // renderer.rs:128-130: the depth budget is spent, the child returns `environment`
+            if (valid) Q.rad[p.slot] = make_float4(q.thr.x * S.env[0], q.thr.y * S.env[1], q.thr.z * S.env[2], 0.0f);
+        } else {
+            uint32_t idx = wave_push(valid, &Q.ctr[seg + 1u].ray_count);
+            if (valid) store_ray(out, idx, q);
+        }
+    }
+    if (COUNT) {
+        unsigned long long s = wave_sum(n_shaded), x = wave_sum(texel_fetches);
+        if (lane_id() == 0) {
+            atomicAdd(&Q.stats[4], s);
+            atomicAdd(&Q.stats[5], x);
+        }
+    }
+}
+
+// RenderResult::add (renderer.rs:355-368) for a whole batch: accum[pixel] += sum over the batch's
+// passes, in ascending pass order.
+__global__ __launch_bounds__(BLOCK) void k_resolve(Queues Q, float *accum, uint32_t npix, uint32_t n_batch_passes) {
+    uint32_t stride = gridDim.x * BLOCK;
+    for (uint32_t pix = blockIdx.x * BLOCK + threadIdx.x; pix < npix; pix += stride) {
+        float r = accum[3 * (size_t)pix], g = accum[3 * (size_t)pix + 1], b = accum[3 * (size_t)pix + 2];
+        for (uint32_t k = 0; k < n_batch_passes; ++k) {
+            float4 v = Q.rad[(size_t)k * npix + pix];
+            r += v.x;
+            g += v.y;
+            b += v.z;
+        }
+        accum[3 * (size_t)pix] = r;
+        accum[3 * (size_t)pix + 1] = g;
+        accum[3 * (size_t)pix + 2] = b;
+    }
+}
+
+// RenderResult::get_raw, renderer.rs:378-402
+__global__ __launch_bounds__(BLOCK) void k_tonemap(const float *accum, size_t n, float scale1, uint8_t *out) {
+    size_t stride = (size_t)gridDim.x * BLOCK;
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        float v = sqrtf(accum[i] * scale1) * 256.0f;
+        uint8_t o;
+        if (v != v) o = 0;
+        else o = (uint8_t)fminf(fmaxf(v, 0.5f), 255.5f);
+        out[i] = o;
+    }
+}
+
+// Closest hit of explicit rays (or of the deterministic primary rays when origin == nullptr).
+__global__ __launch_bounds__(BLOCK) void k_trace_rays(SceneDev S, Queues Q, uint32_t n, const float *origin, const float *dir,
+                                                      uint32_t *prim_out, float *t_out) {
+    __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
+    Stack st;
+    st.lds = lds_stack + threadIdx.x;
+    st.stride = BLOCK;
+    st.spill = Q.spill + (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    st.spill_stride = Q.spill_stride;
+    st.sp = 0;
+    uint32_t stride = gridDim.x * BLOCK;
+    TraceCounters cnt;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        V3 o, d;
+        if (origin) {
+            o = v3(origin[3 * (size_t)i], origin[3 * (size_t)i + 1], origin[3 * (size_t)i + 2]);
+            d = v3(dir[3 * (size_t)i], dir[3 * (size_t)i + 1], dir[3 * (size_t)i + 2]);
+        } else {
+            camera_ray(S, i, 0u, true, o, d);
+        }
+        Best best;
+        traverse<false>(S, o, d, st, best, cnt);
+        prim_out[i] = best.prim;
+        t_out[i] = best.t;
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------------
+thread_local std::string g_error;
+
+int set_error(int code, const std::string &msg) {
+    g_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                          \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess)                                                                                  \
+            return set_error(V4R_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                    \
+    } while (0)
+
+}  // namespace
+
+struct v4r_renderer {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    SceneDev S{};
+    Queues Q{};
+    std::vector<void *> allocations;
+    float *accum_own = nullptr, *accum = nullptr;
+    uint8_t *tonemap_buf = nullptr;
+    uint32_t npix = 0, n_passes = 0, batch_passes = 1;
+    uint32_t grid_trace = 0, grid_shade = 0, grid_stream = 0;
+    bool counting = false;
+    bool has_class[CLS_COUNT] = {false, false, false, false, false, false};
+    size_t ctr_bytes = 0;
+
+    template <class T>
+    int alloc(T **out, size_t count) {
+        void *p = nullptr;
+        size_t bytes = std::max<size_t>(count * sizeof(T), 256);
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) return set_error(V4R_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+        allocations.push_back(p);
+        *out = (T *)p;
+        return V4R_OK;
+    }
+    template <class T>
+    int upload(const T **out, const T *src, size_t count) {
+        T *p = nullptr;
+        if (int rc = alloc(&p, count)) return rc;
+        if (count) {
+            hipError_t e = hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice);
+            if (e != hipSuccess) return set_error(V4R_E_HIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
+        }
+        *out = p;
+        return V4R_OK;
+    }
+};
+
+namespace {
+
+// Does the texture tree rooted at `tex` contain Perlin noise?
+bool has_noise(const v4r_scene_desc *d, uint32_t tex) {
+    const v4r_texture &t = d->textures[tex];
+    if (t.kind == V4R_TEX_NOISE) return true;
+    if (t.kind == V4R_TEX_CHECKER) return has_noise(d, t.a) || has_noise(d, t.b);
+    return false;
+}
+
+int validate_prim(const v4r_scene_desc *d, const v4r_prim &p, bool in_medium, const char *what) {
+    uint32_t kind = p.type & V4R_PRIM_TYPE_MASK;
+    if (kind > V4R_PRIM_MEDIUM) return set_error(V4R_E_INVALID, std::string(what) + ": unknown primitive type");
+    if (p.xform != V4R_NO_XFORM && p.xform >= d->n_xforms) return set_error(V4R_E_INVALID, std::string(what) + ": transform index out of range");
+    if (kind == V4R_PRIM_TRIANGLE && p.aux >= d->n_tri_shading) return set_error(V4R_E_INVALID, std::string(what) + ": triangle shading index out of range");
+    if (kind == V4R_PRIM_MEDIUM) {
+        if (in_medium) return set_error(V4R_E_INVALID, std::string(what) + ": nested constant medium");
+        if (p.aux >= d->n_media) return set_error(V4R_E_INVALID, std::string(what) + ": medium index out of range");
+    }
+    return V4R_OK;
+}
+
+// Every index the kernels will follow is checked here, so a malformed table is an error code, not
+// a GPU fault.
+int validate(const v4r_scene_desc *d, uint32_t &depth_out) {
+    if (!d) return set_error(V4R_E_INVALID, "NULL scene description");
+    if (d->abi_version != V4R_ABI_VERSION) return set_error(V4R_E_INVALID, "scene description has a different ABI version");
+    if (d->width == 0 || d->height == 0) return set_error(V4R_E_INVALID, "width and height must be positive");
+    if ((uint64_t)d->width * d->height > (1ull << 28)) return set_error(V4R_E_LIMIT, "image larger than 2^28 pixels");
+    if (d->n_prims > 0x7FFFFFFFu) return set_error(V4R_E_LIMIT, "too many primitives");
+    auto need = [&](const void *p, uint32_t n, const char *name) {
+        return (n != 0 && p == nullptr) ? set_error(V4R_E_INVALID, std::string(name) + " table is NULL") : V4R_OK;
+    };
+    if (int rc = need(d->nodes, d->n_nodes, "nodes")) return rc;
+    if (int rc = need(d->prims, d->n_prims, "prims")) return rc;
+    if (int rc = need(d->prim_material, d->n_prims, "prim_material")) return rc;
+    if (int rc = need(d->xforms, d->n_xforms, "xforms")) return rc;
+    if (int rc = need(d->tri_shading, d->n_tri_shading, "tri_shading")) return rc;
+    if (int rc = need(d->media, d->n_media, "media")) return rc;
+    if (int rc = need(d->medium_prims, d->n_medium_prims, "medium_prims")) return rc;
+    if (int rc = need(d->materials, d->n_materials, "materials")) return rc;
+    if (int rc = need(d->textures, d->n_textures, "textures")) return rc;
+    if (int rc = need(d->images, d->n_images, "images")) return rc;
+    if (int rc = need(d->perlin, d->n_perlin, "perlin")) return rc;
+    if (int rc = need(d->lights, d->n_lights, "lights")) return rc;
+    if (d->n_materials > 0xFFFFFFu) return set_error(V4R_E_LIMIT, "too many materials");
+
+    // BVH: n-1 interior nodes for n >= 2 primitives, every primitive reachable exactly once.
+    if (d->n_prims <= 1) {
+        if (d->n_nodes != 0) return set_error(V4R_E_INVALID, "a scene with fewer than two primitives has no interior BVH node");
+    } else if (d->n_nodes != d->n_prims - 1) {
+        return set_error(V4R_E_INVALID, "BVH must hold exactly n_prims - 1 interior nodes");
+    }
+    depth_out = 0;
+    if (d->n_nodes) {
+        std::vector<uint8_t> seen_node(d->n_nodes, 0), seen_prim(d->n_prims, 0);
+        std::vector<std::pair<uint32_t, uint32_t>> stack{{0u, 1u}};
+        seen_node[0] = 1;
+        while (!stack.empty()) {
+            auto [node, depth] = stack.back();
+            stack.pop_back();
+            depth_out = std::max(depth_out, depth);
+            const v4r_bvh_node &n = d->nodes[node];
+            for (uint32_t c : {n.child0, n.child1}) {
+                if (c & V4R_LEAF_BIT) {
+                    uint32_t p = c & ~V4R_LEAF_BIT;
+                    if (p >= d->n_prims || seen_prim[p]) return set_error(V4R_E_INVALID, "BVH leaf index out of range or repeated");
+                    seen_prim[p] = 1;
+                } else {
+                    if (c >= d->n_nodes || seen_node[c]) return set_error(V4R_E_INVALID, "BVH child index out of range or repeated");
+                    seen_node[c] = 1;
+                    stack.push_back({c, depth + 1});
+                }
+            }
+        }
+    }
+    for (uint32_t i = 0; i < d->n_prims; ++i) {
+        if (int rc = validate_prim(d, d->prims[i], false, "prims")) return rc;
+        if (d->prim_material[i] >= d->n_materials) return set_error(V4R_E_INVALID, "prim_material index out of range");
+    }
+    for (uint32_t i = 0; i < d->n_medium_prims; ++i)
+        if (int rc = validate_prim(d, d->medium_prims[i], true, "medium_prims")) return rc;
+    for (uint32_t i = 0; i < d->n_media; ++i) {
+        const v4r_medium &m = d->media[i];
+        if (m.count == 0 || (uint64_t)m.first + m.count > d->n_medium_prims) return set_error(V4R_E_INVALID, "medium boundary range out of bounds");
+    }
+    for (uint32_t i = 0; i < d->n_textures; ++i) {
+        const v4r_texture &t = d->textures[i];
+        switch (t.kind) {
+            case V4R_TEX_SOLID: break;
+            case V4R_TEX_CHECKER:
+                // children must precede their parent: the table is then acyclic by construction
+                if (t.a >= i || t.b >= i) return set_error(V4R_E_INVALID, "checker children must have lower texture indices");
+                break;
+            case V4R_TEX_IMAGE:
+                if (t.a >= d->n_images) return set_error(V4R_E_INVALID, "image index out of range");
+                break;
+            case V4R_TEX_NOISE:
+                if (t.a >= d->n_perlin) return set_error(V4R_E_INVALID, "perlin table index out of range");
+                break;
+            default: return set_error(V4R_E_INVALID, "unknown texture kind");
+        }
+    }
+    for (uint32_t i = 0; i < d->n_images; ++i) {
+        const v4r_image &im = d->images[i];
+        if (im.width == 0 || im.height == 0 || im.offset + (uint64_t)im.width * im.height * 3 > d->texel_bytes || !d->texels)
+            return set_error(V4R_E_INVALID, "image texels out of bounds");
+    }
+    for (uint32_t i = 0; i < d->n_materials; ++i) {
+        const v4r_material &m = d->materials[i];
+        if (m.kind > V4R_MAT_ISOTROPIC) return set_error(V4R_E_INVALID, "unknown material kind");
+        bool textured = m.kind == V4R_MAT_LAMBERTIAN || m.kind == V4R_MAT_DIFFUSE_LIGHT || m.kind == V4R_MAT_ISOTROPIC;
+        if (textured && m.tex >= d->n_textures) return set_error(V4R_E_INVALID, "material texture index out of range");
+    }
+    for (uint32_t i = 0; i < d->n_lights; ++i) {
+        if (d->lights[i] >= d->n_prims) return set_error(V4R_E_INVALID, "light index out of range");
+        if ((d->prims[d->lights[i]].type & V4R_PRIM_TYPE_MASK) == V4R_PRIM_MEDIUM)
+            return set_error(V4R_E_INVALID, "a constant medium cannot be a light");
+    }
+    if (d->n_media != 0) return set_error(V4R_E_UNSUPPORTED, "constant media are not implemented on the device path yet");
+    return V4R_OK;
+}
+
+uint32_t class_of(const v4r_scene_desc *d, const v4r_material &m) {
+    switch (m.kind) {
+        case V4R_MAT_DIFFUSE_LIGHT: return CLS_LIGHT;
+        case V4R_MAT_LAMBERTIAN: return has_noise(d, m.tex) ? CLS_LAMBERT_NOISE : CLS_LAMBERT;
+        case V4R_MAT_METAL: return CLS_METAL;
+        case V4R_MAT_DIELECTRIC: return CLS_DIELECTRIC;
+        default: return CLS_ISOTROPIC;
+    }
+}
+
+template <class K>
+uint32_t grid_for(K kernel, int n_cu) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    per_cu = std::min(per_cu, 8);
+    return (uint32_t)(n_cu * per_cu);
+}
+
+int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
+    HIP_TRY(hipSetDevice(r->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, r->device));
+    int n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIP_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+
+    SceneDev &S = r->S;
+    if (int rc = r->upload(&S.nodes, (const float4 *)d->nodes, (size_t)d->n_nodes * 4)) return rc;
+    if (int rc = r->upload(&S.prims, (const float4 *)d->prims, (size_t)d->n_prims * 3)) return rc;
+    std::vector<uint32_t> info(d->n_prims);
+    for (uint32_t i = 0; i < d->n_prims; ++i) {
+        uint32_t cls = class_of(d, d->materials[d->prim_material[i]]);
+        info[i] = d->prim_material[i] | (cls << 24);
+        r->has_class[cls] = true;
+    }
+    if (int rc = r->upload(&S.prim_info, info.data(), info.size())) return rc;
+    if (int rc = r->upload(&S.xforms, (const float *)d->xforms, (size_t)d->n_xforms * 24)) return rc;
+    if (int rc = r->upload(&S.tri, (const float4 *)d->tri_shading, (size_t)d->n_tri_shading * 4)) return rc;
+    if (int rc = r->upload(&S.media, (const uint4 *)d->media, (size_t)d->n_media)) return rc;
+    if (int rc = r->upload(&S.medium_prims, (const float4 *)d->medium_prims, (size_t)d->n_medium_prims * 3)) return rc;
+    if (int rc = r->upload(&S.materials, (const uint32_t *)d->materials, (size_t)d->n_materials * 8)) return rc;
+    if (int rc = r->upload(&S.textures, (const uint32_t *)d->textures, (size_t)d->n_textures * 8)) return rc;
+    // images: RGB8 -> one RGBA8 word per texel so a fetch is a single aligned load
+    std::vector<uint4> images(d->n_images);
+    std::vector<uint32_t> texels;
+    for (uint32_t i = 0; i < d->n_images; ++i) {
+        const v4r_image &im = d->images[i];
+        images[i] = make_uint4((uint32_t)texels.size(), im.width, im.height, 0u);
+        const uint8_t *src = d->texels + im.offset;
+        size_t n = (size_t)im.width * im.height;
+        if (texels.size() + n > 0xFFFFFFFFull) return set_error(V4R_E_LIMIT, "more than 2^32 texels");
+        for (size_t k = 0; k < n; ++k) texels.push_back(src[3 * k] | (src[3 * k + 1] << 8) | ((uint32_t)src[3 * k + 2] << 16));
+    }
+    if (int rc = r->upload(&S.images, images.data(), images.size())) return rc;
+    if (int rc = r->upload(&S.texels, texels.data(), texels.size())) return rc;
+    std::vector<float4> pvec((size_t)d->n_perlin * 256);
+    std::vector<uint8_t> pperm((size_t)d->n_perlin * 768);
+    for (uint32_t i = 0; i < d->n_perlin; ++i) {
+        for (int k = 0; k < 256; ++k) pvec[(size_t)i * 256 + k] = make_float4(d->perlin[i].vec[k][0], d->perlin[i].vec[k][1], d->perlin[i].vec[k][2], 0.0f);
+        std::memcpy(&pperm[(size_t)i * 768], d->perlin[i].perm_x, 256);
+        std::memcpy(&pperm[(size_t)i * 768 + 256], d->perlin[i].perm_y, 256);
+        std::memcpy(&pperm[(size_t)i * 768 + 512], d->perlin[i].perm_z, 256);
+    }
+    if (int rc = r->upload(&S.perlin_vec, pvec.data(), pvec.size())) return rc;
+    if (int rc = r->upload(&S.perlin_perm, pperm.data(), pperm.size())) return rc;
+    if (int rc = r->upload(&S.lights, d->lights, (size_t)d->n_lights)) return rc;
+    S.n_nodes = d->n_nodes;
+    S.n_prims = d->n_prims;
+    S.n_lights = d->n_lights;
+    S.flags = d->flags;
+    std::memcpy(S.bg, d->background, sizeof S.bg);
+    std::memcpy(S.env, d->environment, sizeof S.env);
+    S.cam = d->camera;
+    S.width = d->width;
+    S.height = d->height;
+    S.max_depth = d->max_depth;
+    S.antialias = d->antialias;
+
+    // queues
+    r->npix = d->width * d->height;
+    size_t target = 4u << 20;  // paths per batch
+    if (const char *env = std::getenv("V4R_BATCH_PATHS")) {
+        long long v = std::atoll(env);
+        if (v > 0) target = (size_t)v;
+    }
+    r->batch_passes = (uint32_t)std::max<size_t>(1, std::min<size_t>(target / r->npix, 4096));
+    if ((uint64_t)r->batch_passes * r->npix > 0x7FFFFFFFull) r->batch_passes = (uint32_t)(0x7FFFFFFFull / r->npix);
+    Queues &Q = r->Q;
+    Q.cap = r->batch_passes * r->npix;
+    for (int p = 0; p < 2; ++p)
+        for (int c = 0; c < 3; ++c)
+            if (int rc = r->alloc(&Q.ray[p][c], Q.cap)) return rc;
+    for (int k = 0; k < CLS_COUNT; ++k)
+        for (int c = 0; c < 4; ++c)
+            if (int rc = r->alloc(&Q.hit[k][c], r->has_class[k] ? Q.cap : 1)) return rc;
+    if (int rc = r->alloc(&Q.rad, Q.cap)) return rc;
+    r->ctr_bytes = sizeof(SegCtr) * ((size_t)d->max_depth + 1);
+    if (int rc = r->alloc(&Q.ctr, (size_t)d->max_depth + 1)) return rc;
+    HIP_TRY(hipMemset(Q.ctr, 0, r->ctr_bytes));
+    if (int rc = r->alloc(&Q.stats, 8)) return rc;
+    HIP_TRY(hipMemset(Q.stats, 0, 64));
+
+    r->grid_trace = std::max(grid_for(k_trace<false>, n_cu), grid_for(k_trace_rays, n_cu));
+    r->grid_shade = (uint32_t)n_cu * 8u;
+    r->grid_stream = (uint32_t)n_cu * 8u;
+    uint32_t spill_depth = bvh_depth > (uint32_t)LDS_DEPTH ? bvh_depth - LDS_DEPTH : 0;
+    Q.spill_stride = r->grid_trace * BLOCK;
+    if (int rc = r->alloc(&Q.spill, (size_t)Q.spill_stride * std::max(spill_depth, 1u))) return rc;
+
+    if (int rc = r->alloc(&r->accum_own, (size_t)r->npix * 3)) return rc;
+    HIP_TRY(hipMemset(r->accum_own, 0, (size_t)r->npix * 3 * sizeof(float)));
+    r->accum = r->accum_own;
+    if (int rc = r->alloc(&r->tonemap_buf, (size_t)r->npix * 3)) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    return V4R_OK;
+}
+
+template <int CLS>
+void launch_shade(v4r_renderer *r, uint32_t seg) {
+    if (!r->has_class[CLS]) return;
+    Queues Q = r->Q;
+    if (r->counting) hipLaunchKernelGGL((k_shade<CLS, true>), dim3(r->grid_shade), dim3(BLOCK), 0, r->stream, r->S, Q, seg);
+    else hipLaunchKernelGGL((k_shade<CLS, false>), dim3(r->grid_shade), dim3(BLOCK), 0, r->stream, r->S, Q, seg);
+}
+
+int run_batch(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_t pass_stride, uint32_t n_batch_passes) {
+    Queues Q = r->Q;
+    if (!r->counting) Q.stats = nullptr;
+    uint32_t n_paths = n_batch_passes * r->npix;
+    HIP_TRY(hipMemsetAsync(r->Q.ctr, 0, r->ctr_bytes, r->stream));
+    hipLaunchKernelGGL(k_raygen, dim3(r->grid_stream), dim3(BLOCK), 0, r->stream, r->S, Q, (uint32_t)seed, (uint32_t)(seed >> 32),
+                       first_pass, pass_stride, n_paths);
+    for (uint32_t seg = 0; seg < r->S.max_depth; ++seg) {
+        if (r->counting) hipLaunchKernelGGL(k_trace<true>, dim3(r->grid_trace), dim3(BLOCK), 0, r->stream, r->S, r->Q, seg);
+        else hipLaunchKernelGGL(k_trace<false>, dim3(r->grid_trace), dim3(BLOCK), 0, r->stream, r->S, r->Q, seg);
+        launch_shade<CLS_LIGHT>(r, seg);
+        launch_shade<CLS_LAMBERT>(r, seg);
+        launch_shade<CLS_LAMBERT_NOISE>(r, seg);
+        launch_shade<CLS_METAL>(r, seg);
+        launch_shade<CLS_DIELECTRIC>(r, seg);
+        launch_shade<CLS_ISOTROPIC>(r, seg);
+    }
+    hipLaunchKernelGGL(k_resolve, dim3(r->grid_stream), dim3(BLOCK), 0, r->stream, r->Q, r->accum, r->npix, n_batch_passes);
+    HIP_TRY(hipGetLastError());
+    return V4R_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t v4r_abi_version(void) { return V4R_ABI_VERSION; }
+const char *v4r_last_error(void) { return g_error.c_str(); }
+
+int v4r_renderer_create(const v4r_scene_desc *desc, int device, v4r_renderer **out) {
+    if (!out) return set_error(V4R_E_INVALID, "NULL output pointer");
+    *out = nullptr;
+    uint32_t depth = 0;
+    if (int rc = validate(desc, depth)) return rc;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return set_error(V4R_E_NO_DEVICE, "no HIP device is visible");
+    if (device < 0 || device >= count) return set_error(V4R_E_NO_DEVICE, "HIP device index out of range");
+    v4r_renderer *r = new v4r_renderer();
+    r->device = device;
+    int rc = build(r, desc, depth);
+    if (rc != V4R_OK) {
+        std::string keep = g_error;
+        v4r_renderer_destroy(r);
+        g_error = keep;
+        return rc;
+    }
+    *out = r;
+    return V4R_OK;
+}
+
+void v4r_renderer_destroy(v4r_renderer *r) {
+    if (!r) return;
+    (void)hipSetDevice(r->device);
+    if (r->stream) {
+        (void)hipStreamSynchronize(r->stream);
+        (void)hipStreamDestroy(r->stream);
+    }
+    for (void *p : r->allocations) (void)hipFree(p);
+    delete r;
+}
+
+int v4r_render(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_t pass_stride, uint32_t n_passes) {
+    if (!r) return set_error(V4R_E_INVALID, "NULL renderer");
+    if (pass_stride == 0) pass_stride = 1;
+    HIP_TRY(hipSetDevice(r->device));
+    uint32_t done = 0;
+    while (done < n_passes) {
+        uint32_t nb = std::min(r->batch_passes, n_passes - done);
+        if (int rc = run_batch(r, seed, first_pass + done * pass_stride, pass_stride, nb)) return rc;
+        done += nb;
+    }
+    r->n_passes += n_passes;
+    return V4R_OK;
+}
+
+int v4r_accum_bind(v4r_renderer *r, float *device_hwc) {
+    if (!r) return set_error(V4R_E_INVALID, "NULL renderer");
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    r->accum = device_hwc ? device_hwc : r->accum_own;
+    return V4R_OK;
+}
+
+int v4r_accum_clear(v4r_renderer *r) {
+    if (!r) return set_error(V4R_E_INVALID, "NULL renderer");
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipMemsetAsync(r->accum, 0, (size_t)r->npix * 3 * sizeof(float), r->stream));
+    r->n_passes = 0;
+    return V4R_OK;
+}
+
+int v4r_accum_read(v4r_renderer *r, float *host_hwc, uint32_t *n_passes) {
+    if (!r) return set_error(V4R_E_INVALID, "NULL renderer");
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    if (host_hwc) HIP_TRY(hipMemcpy(host_hwc, r->accum, (size_t)r->npix * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (n_passes) *n_passes = r->n_passes;
+    return V4R_OK;
+}
+
+int v4r_accum_device(v4r_renderer *r, float **device_hwc, uint64_t *n_floats) {
+    if (!r) return set_error(V4R_E_INVALID, "NULL renderer");
+    if (device_hwc) *device_hwc = r->accum;
+    if (n_floats) *n_floats = (uint64_t)r->npix * 3;
+    return V4R_OK;
+}
+
+int v4r_tonemap_u8(v4r_renderer *r, uint32_t n_passes, uint8_t *host_rgb) {
+    if (!r || !host_rgb) return set_error(V4R_E_INVALID, "NULL argument");
+    if (n_passes == 0) return set_error(V4R_E_INVALID, "no passes to average");
+    HIP_TRY(hipSetDevice(r->device));
+    size_t n = (size_t)r->npix * 3;
+    hipLaunchKernelGGL(k_tonemap, dim3(r->grid_stream), dim3(BLOCK), 0, r->stream, r->accum, n, 1.0f / (float)n_passes, r->tonemap_buf);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    HIP_TRY(hipMemcpy(host_rgb, r->tonemap_buf, n, hipMemcpyDeviceToHost));
+    return V4R_OK;
+}
+
+static int trace_common(v4r_renderer *r, uint32_t n, const float *host_origin, const float *host_dir, uint32_t *host_prim_id, float *host_t) {
+    HIP_TRY(hipSetDevice(r->device));
+    if (n == 0) return V4R_OK;
+    float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr;
+    uint32_t *d_p = nullptr;
+    auto cleanup = [&]() {
+        (void)hipFree(d_o);
+        (void)hipFree(d_d);
+        (void)hipFree(d_t);
+        (void)hipFree(d_p);
+    };
+    hipError_t e = hipSuccess;
+    if (host_origin) {
+        e = hipMalloc((void **)&d_o, (size_t)n * 3 * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void **)&d_d, (size_t)n * 3 * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(d_o, host_origin, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_d, host_dir, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess) e = hipMalloc((void **)&d_t, (size_t)n * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_p, (size_t)n * sizeof(uint32_t));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_trace_rays, dim3(r->grid_trace), dim3(BLOCK), 0, r->stream, r->S, r->Q, n, d_o, d_d, d_p, d_t);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
+    if (e == hipSuccess && host_prim_id) e = hipMemcpy(host_prim_id, d_p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && host_t) e = hipMemcpy(host_t, d_t, (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
+    cleanup();
+    if (e != hipSuccess) return set_error(V4R_E_HIP, std::string("trace: ") + hipGetErrorString(e));
+    return V4R_OK;
+}
+
+int v4r_trace_primary(v4r_renderer *r, uint32_t *host_prim_id, float *host_t) {
+    if (!r) return set_error(V4R_E_INVALID, "NULL renderer");
+    return trace_common(r, r->npix, nullptr, nullptr, host_prim_id, host_t);
+}
+
+int v4r_trace_rays(v4r_renderer *r, uint32_t n, const float *host_origin, const float *host_dir, uint64_t seed,
+                   uint32_t *host_prim_id, float *host_t) {
+    (void)seed;  // keys the constant-medium draw once media run on the device
+    if (!r) return set_error(V4R_E_INVALID, "NULL renderer");
+    if (n && (!host_origin || !host_dir)) return set_error(V4R_E_INVALID, "NULL ray arrays");
+    return trace_common(r, n, host_origin, host_dir, host_prim_id, host_t);
+}
+
+int v4r_stats_enable(v4r_renderer *r, int on) {
+    if (!r) return set_error(V4R_E_INVALID, "NULL renderer");
+    r->counting = on != 0;
+    return V4R_OK;
+}
+
+int v4r_stats_read(v4r_renderer *r, v4r_stats *out, int reset) {
+    if (!r || !out) return set_error(V4R_E_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    unsigned long long h[8];
+    HIP_TRY(hipMemcpy(h, r->Q.stats, sizeof h, hipMemcpyDeviceToHost));
+    out->segments = h[0];
+    out->nodes = h[1];
+    out->prims = h[2];
+    out->paths = h[3];
+    out->shaded = h[4];
+    out->texel_fetches = h[5];
+    if (reset) HIP_TRY(hipMemset(r->Q.stats, 0, 64));
+    return V4R_OK;
+}
+
+int v4r_synchronize(v4r_renderer *r) {
+    if (!r) return set_error(V4R_E_INVALID, "NULL renderer");
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    return V4R_OK;
+}
+
+int v4r_stream(v4r_renderer *r, void **hip_stream) {
+    if (!r || !hip_stream) return set_error(V4R_E_INVALID, "NULL argument");
+    *hip_stream = (void *)r->stream;
+    return V4R_OK;
+}
+
+int v4r_pass_count(v4r_renderer *r, uint32_t *n_passes) {
+    if (!r || !n_passes) return set_error(V4R_E_INVALID, "NULL argument");
+    *n_passes = r->n_passes;
+    return V4R_OK;
+}
+
+}  // extern "C"

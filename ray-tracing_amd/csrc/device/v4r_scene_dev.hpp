@@ -1,0 +1,566 @@
+// Device-side scene view and the per-ray device functions: slab test, primitive intersection,
+// BVH traversal, hit reconstruction, textures, pdfs and materials.  Each function cites the
+// reference lines (under the reference tree's src/) whose arithmetic it implements.
+#pragma once
+#include "v4r_math.hpp"
+#include "v4ray_hip.h"
+
+namespace v4r {
+
+// Shading classes: rays are binned by the class of the material they hit so that each shading
+// kernel runs one material's code on full waves.
+enum {
+    CLS_LIGHT = 0,          // DiffuseLight: emits, never scatters
+    CLS_LAMBERT = 1,        // Lambertian with solid / checker / image textures
+    CLS_LAMBERT_NOISE = 2,  // Lambertian whose texture tree contains Perlin noise (ALU heavy)
+    CLS_METAL = 3,
+    CLS_DIELECTRIC = 4,
+    CLS_ISOTROPIC = 5,
+    CLS_COUNT = 6
+};
+
+constexpr uint32_t NO_PRIM = 0xFFFFFFFFu;
+
+struct SceneDev {
+    const float4 *nodes;         // 4 x float4 per node (v4r_bvh_node)
+    const float4 *prims;         // 3 x float4 per primitive (v4r_prim)
+    const uint32_t *prim_info;   // material index | shading class << 24
+    const float *xforms;         // 24 floats per transform (v4r_xform)
+    const float4 *tri;           // 4 x float4 per triangle (v4r_tri_shading)
+    const uint4 *media;          // v4r_medium
+    const float4 *medium_prims;  // 3 x float4 per boundary primitive
+    const uint32_t *materials;   // 8 words per material (v4r_material)
+    const uint32_t *textures;    // 8 words per texture (v4r_texture)
+    const uint4 *images;         // {first texel, width, height, 0}
+    const uint32_t *texels;      // RGBA8, one word per texel
+    const float4 *perlin_vec;    // 256 x float4 per table
+    const uint8_t *perlin_perm;  // 768 bytes per table: perm_x, perm_y, perm_z
+    const uint32_t *lights;      // primitive indices
+    uint32_t n_nodes, n_prims, n_lights, flags;
+    float bg[3], env[3];
+    v4r_camera cam;
+    uint32_t width, height, max_depth, antialias;
+};
+
+struct RayD {
+    V3 o, d;
+};
+
+// Full hit record (HitRecord, hittable/mod.rs:24-32) as shading needs it.
+struct HitD {
+    V3 p, normal;
+    float u, v;
+    bool front;
+};
+
+struct Prim {
+    float4 a, b, c;
+    __device__ __forceinline__ uint32_t type() const { return __float_as_uint(c.y); }
+    __device__ __forceinline__ uint32_t xform() const { return __float_as_uint(c.z); }
+    __device__ __forceinline__ uint32_t aux() const { return __float_as_uint(c.w); }
+};
+V4R_DEV Prim load_prim(const float4 *prims, uint32_t i) {
+    const float4 *p = prims + 3 * (size_t)i;
+    return Prim{p[0], p[1], p[2]};
+}
+
+// ---- Ray::intersects_aabb, ray.rs:167-189 -------------------------------------------------------
+// Same running-interval test with strict tmin < tmax; the per-axis divisions become multiplications
+// by a reciprocal computed once per ray.
+V4R_DEV bool slab(V3 lo, V3 hi, V3 o, V3 inv, float &entry) {
+    float t_min = EPSILON, t_max = V4R_INF;
+    float a0 = (lo.x - o.x) * inv.x, a1 = (hi.x - o.x) * inv.x;
+    t_min = fmaxf(fminf(a0, a1), t_min);
+    t_max = fminf(fmaxf(a0, a1), t_max);
+    bool ok = t_min < t_max;
+    float b0 = (lo.y - o.y) * inv.y, b1 = (hi.y - o.y) * inv.y;
+    t_min = fmaxf(fminf(b0, b1), t_min);
+    t_max = fminf(fmaxf(b0, b1), t_max);
+    ok = ok && (t_min < t_max);
+    float c0 = (lo.z - o.z) * inv.z, c1 = (hi.z - o.z) * inv.z;
+    t_min = fmaxf(fminf(c0, c1), t_min);
+    t_max = fminf(fmaxf(c0, c1), t_max);
+    ok = ok && (t_min < t_max);
+    entry = t_min;
+    return ok;
+}
+
+// ---- primitive intersection (distance only) -----------------------------------------------------
+// Sphere::hit, hittable/sphere.rs:60-79
+V4R_DEV bool sphere_t(const Prim &pr, V3 o, V3 d, float t_min, float t_max, float &t) {
+    V3 oc = o - v3(pr.a.x, pr.a.y, pr.a.z);
+    float half_b = dot(oc, d);
+    float c = norm2(oc) - pr.a.w * pr.a.w;
+    float disc = half_b * half_b - c;
+    if (disc < 0.0f) return false;
+    float sqrt_d = sqrtf(disc);
+    float root1 = -half_b - sqrt_d;
+    bool m1 = root1 >= t_min && root1 <= t_max;
+    float root2 = -half_b + sqrt_d;
+    bool m2 = root2 >= t_min && root2 <= t_max;
+    t = m1 ? root1 : root2;
+    return m1 || m2;
+}
+
+V4R_DEV void rect_axes(uint32_t type, int &ia, int &ib, int &ik) {
+    uint32_t k = type & V4R_PRIM_TYPE_MASK;
+    ia = k == V4R_PRIM_XY_RECT ? 0 : (k == V4R_PRIM_YZ_RECT ? 1 : 2);
+    ib = k == V4R_PRIM_XY_RECT ? 1 : (k == V4R_PRIM_YZ_RECT ? 2 : 0);
+    ik = k == V4R_PRIM_XY_RECT ? 2 : (k == V4R_PRIM_YZ_RECT ? 0 : 1);
+}
+
+// $ty::hit, hittable/aa_rect.rs:114-129
+V4R_DEV bool rect_t(const Prim &pr, V3 o, V3 d, float t_min, float t_max, float &t) {
+    int ia, ib, ik;
+    rect_axes(pr.type(), ia, ib, ik);
+    t = (pr.b.x - comp(o, ik)) / comp(d, ik);
+    float a = comp(o, ia) + t * comp(d, ia);
+    float b = comp(o, ib) + t * comp(d, ib);
+    return t >= t_min && t <= t_max && a >= pr.a.x && a <= pr.a.y && b >= pr.a.z && b <= pr.a.w;
+}
+
+// Triangle::hit, hittable/triangle.rs:56-80
+V4R_DEV bool tri_t(const Prim &pr, V3 o, V3 d, float t_min, float t_max, float &t, float &u, float &v, float &det) {
+    V3 v0 = v3(pr.a.x, pr.a.y, pr.a.z), e12 = v3(pr.a.w, pr.b.x, pr.b.y), e13 = v3(pr.b.z, pr.b.w, pr.c.x);
+    V3 p_vec = cross(d, e13);
+    det = dot(e12, p_vec);
+    float inv_det = 1.0f / det;
+    V3 t_vec = o - v0;
+    u = inv_det * dot(t_vec, p_vec);
+    V3 q_vec = cross(t_vec, e12);
+    v = inv_det * dot(d, q_vec);
+    t = inv_det * dot(e13, q_vec);
+    return fabsf(det) > 0.0f && !(u < 0.0f) && u <= 1.0f && !(v < 0.0f) && (u + v) <= 1.0f && t >= t_min && t <= t_max;
+}
+
+// TransformHittable::hit prologue, hittable/transform.rs:69-76
+V4R_DEV void to_object(const float *x, V3 &o, V3 &d, float &nrm) {
+    const float *inv = x + 12;
+    V3 dir = mat_mul(inv, d);
+    nrm = norm(dir);
+    o = mat_mul(inv, o) + v3(inv[9], inv[10], inv[11]);
+    d = dir / nrm;
+}
+
+struct TraceCounters {
+    uint32_t nodes = 0, prims = 0;
+};
+
+// Closest hit so far during traversal.
+struct Best {
+    float t;
+    uint32_t prim;
+    float u, v;  // triangle barycentrics
+};
+
+// One primitive against the ray over [EPSILON, +inf) (renderer.rs:167) with the closest-hit rule
+// of renderer.rs:174 (strictly smaller t wins; equal t keeps the lowest index).
+V4R_DEV void consider(const SceneDev &S, uint32_t prim_index, V3 o, V3 d, Best &best) {
+    Prim pr = load_prim(S.prims, prim_index);
+    float nrm = 1.0f;
+    uint32_t xf = pr.xform();
+    if (xf != V4R_NO_XFORM) to_object(S.xforms + 24 * (size_t)xf, o, d, nrm);
+    float t_min = EPSILON * nrm, t_max = V4R_INF * nrm;
+    float t = 0.0f, u = 0.0f, v = 0.0f, det;
+    bool hit;
+    uint32_t kind = pr.type() & V4R_PRIM_TYPE_MASK;
+    if (kind == V4R_PRIM_SPHERE) hit = sphere_t(pr, o, d, t_min, t_max, t);
+    else if (kind == V4R_PRIM_TRIANGLE) hit = tri_t(pr, o, d, t_min, t_max, t, u, v, det);
+    else if (kind <= V4R_PRIM_ZX_RECT) hit = rect_t(pr, o, d, t_min, t_max, t);
+    else hit = false;
+    if (xf != V4R_NO_XFORM) t = t / nrm;  // transform.rs:90
+    if (hit && (t < best.t || (t == best.t && prim_index < best.prim))) {
+        best.t = t;
+        best.prim = prim_index;
+        best.u = u;
+        best.v = v;
+    }
+}
+
+// Stack of the traversal: the first LDS_DEPTH entries of each lane live in LDS (conflict-free:
+// entry e of thread t sits at [e][t]); deeper entries spill to a per-thread slab in HBM.
+constexpr int LDS_DEPTH = 12;
+struct Stack {
+    uint2 *lds;        // this thread's column: lds[e * block_dim]
+    uint32_t stride;   // block_dim
+    uint2 *spill;      // this thread's column in the global slab: spill[e * spill_stride]
+    size_t spill_stride;
+    int sp;
+    __device__ __forceinline__ void push(uint32_t node, float entry) {
+        uint2 v = make_uint2(node, __float_as_uint(entry));
+        if (sp < LDS_DEPTH) lds[(uint32_t)sp * stride] = v;
+        else spill[(size_t)(sp - LDS_DEPTH) * spill_stride] = v;
+        ++sp;
+    }
+    __device__ __forceinline__ uint2 pop() {
+        --sp;
+        return sp < LDS_DEPTH ? lds[(uint32_t)sp * stride] : spill[(size_t)(sp - LDS_DEPTH) * spill_stride];
+    }
+};
+
+// BVH::traverse (bvh/bvh.rs:182-239) + closest-hit selection (renderer.rs:149-183), restructured
+// for a GPU lane: near child first, far child stacked with its entry distance, subtrees skipped
+// once their entry distance exceeds the closest hit.  The closest hit is the same one the
+// reference's candidate-set traversal selects.
+template <bool COUNT>
+V4R_DEV void traverse(const SceneDev &S, V3 o, V3 d, Stack &st, Best &best, TraceCounters &cnt) {
+    best.t = V4R_INF;
+    best.prim = NO_PRIM;
+    best.u = best.v = 0.0f;
+    if (S.n_prims == 0) return;
+    if (S.n_nodes == 0) {  // single shape: tested without any box (bvh.rs:218-224)
+        if (COUNT) cnt.prims++;
+        consider(S, 0, o, d, best);
+        return;
+    }
+    V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    uint32_t node = 0;
+    st.sp = 0;
+    while (true) {
+        const float4 *np = S.nodes + 4 * (size_t)node;
+        float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+        if (COUNT) cnt.nodes++;
+        float e0, e1;
+        bool h0 = slab(v3(n0.x, n0.y, n0.z), v3(n0.w, n1.x, n1.y), o, inv, e0) && e0 <= best.t;
+        bool h1 = slab(v3(n1.z, n1.w, n2.x), v3(n2.y, n2.z, n2.w), o, inv, e1) && e1 <= best.t;
+        uint32_t c0 = __float_as_uint(n3.x), c1 = __float_as_uint(n3.y);
+        if (h0 && (c0 & V4R_LEAF_BIT)) {
+            if (COUNT) cnt.prims++;
+            consider(S, c0 & ~V4R_LEAF_BIT, o, d, best);
+            h0 = false;
+        }
+        if (h1 && (c1 & V4R_LEAF_BIT)) {
+            if (e1 <= best.t) {
+                if (COUNT) cnt.prims++;
+                consider(S, c1 & ~V4R_LEAF_BIT, o, d, best);
+            }
+            h1 = false;
+        }
+        if (h0 && h1) {
+            bool first0 = e0 <= e1;
+            st.push(first0 ? c1 : c0, first0 ? e1 : e0);
+            node = first0 ? c0 : c1;
+            continue;
+        }
+        if (h0 || h1) {
+            node = h0 ? c0 : c1;
+            if ((h0 ? e0 : e1) <= best.t) continue;
+        }
+        bool found = false;
+        while (st.sp > 0) {
+            uint2 e = st.pop();
+            if (__uint_as_float(e.y) <= best.t) {
+                node = e.x;
+                found = true;
+                break;
+            }
+        }
+        if (!found) return;
+    }
+}
+
+// ---- hit reconstruction -------------------------------------------------------------------------
+// HitRecord::face_normal, hittable/mod.rs:146-154
+V4R_DEV void face_normal(V3 dir, V3 outward, bool &front, V3 &normal) {
+    front = dot(dir, outward) < 0.0f;
+    normal = front ? outward : -outward;
+}
+// sphere_uv, hittable/sphere.rs:38-45
+V4R_DEV void sphere_uv(V3 p, float &u, float &v) {
+    float theta = acosf(-p.y);
+    float phi = atan2f(-p.z, p.x) + PI;
+    u = phi / TWO_PI;
+    v = theta * FRAC_1_PI;
+}
+
+// Rebuild the full hit record of primitive `prim_index` at world distance t (and triangle
+// barycentrics bu,bv) for the ray (o,d): the second half of each Hittable::hit
+// (sphere.rs:80-92, aa_rect.rs:130-143, triangle.rs:81-94) and the epilogue of
+// TransformHittable::hit (transform.rs:85-93).  uv is produced only when `want_uv`.
+V4R_DEV HitD reconstruct(const SceneDev &S, uint32_t prim_index, V3 o, V3 d, float t, float bu, float bv, bool want_uv) {
+    Prim pr = load_prim(S.prims, prim_index);
+    uint32_t xf = pr.xform();
+    const float *x = nullptr;
+    float nrm = 1.0f;
+    if (xf != V4R_NO_XFORM) {
+        x = S.xforms + 24 * (size_t)xf;
+        to_object(x, o, d, nrm);
+        t = t * nrm;
+    }
+    HitD h;
+    h.u = h.v = 0.0f;
+    h.p = o + d * t;
+    uint32_t kind = pr.type() & V4R_PRIM_TYPE_MASK;
+    if (kind == V4R_PRIM_SPHERE) {
+        V3 outward = normalize(h.p - v3(pr.a.x, pr.a.y, pr.a.z));
+        face_normal(d, outward, h.front, h.normal);
+        if (want_uv) sphere_uv(outward, h.u, h.v);
+    } else if (kind == V4R_PRIM_TRIANGLE) {
+        const float4 *tp = S.tri + 4 * (size_t)pr.aux();
+        float4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3];
+        // n0 = q0.xyz, n1 = (q0.w,q1.x,q1.y), n2 = (q1.z,q1.w,q2.x); uv0 = (q2.y,q2.z), uv1 = (q2.w,q3.x), uv2 = (q3.y,q3.z)
+        float w = 1.0f - bu - bv;
+        h.normal = normalize(v3(q0.x, q0.y, q0.z) * w + v3(q0.w, q1.x, q1.y) * bu + v3(q1.z, q1.w, q2.x) * bv);
+        h.u = q2.y * w + q2.w * bu + q3.y * bv;
+        h.v = q2.z * w + q3.x * bu + q3.z * bv;
+        V3 e12 = v3(pr.a.w, pr.b.x, pr.b.y), e13 = v3(pr.b.z, pr.b.w, pr.c.x);
+        h.front = dot(e12, cross(d, e13)) > 0.0f;  // triangle.rs:92
+    } else if (kind <= V4R_PRIM_ZX_RECT) {
+        int ia, ib, ik;
+        rect_axes(pr.type(), ia, ib, ik);
+        float a = comp(o, ia) + t * comp(d, ia);
+        float b = comp(o, ib) + t * comp(d, ib);
+        h.u = (a - pr.a.x) / (pr.a.y - pr.a.x);
+        h.v = (b - pr.a.z) / (pr.a.w - pr.a.z);
+        float s = (pr.type() & V4R_PRIM_POSITIVE) ? 1.0f : -1.0f;
+        V3 outward = v3(ik == 0 ? s : 0.0f, ik == 1 ? s : 0.0f, ik == 2 ? s : 0.0f);
+        face_normal(d, outward, h.front, h.normal);
+    } else {  // constant medium, constant_medium.rs:77-84
+        h.normal = v3(1, 0, 0);
+        h.front = true;
+    }
+    if (x) {
+        h.p = mat_mul(x, h.p) + v3(x[9], x[10], x[11]);
+        h.normal = normalize(mat_mul(x, h.normal));
+    }
+    return h;
+}
+
+// ---- textures -----------------------------------------------------------------------------------
+V4R_DEV int f32_to_i32_sat(float x) {  // Rust `as isize`, narrowed: only the low 8 bits are used
+    // Beyond the i32 range an f32 is a multiple of 256, so the low 8 bits of the reference's isize
+    // are zero there; NaN converts to 0.
+    if (!(fabsf(x) < 2147483648.0f)) return 0;
+    return (int)x;
+}
+V4R_DEV uint32_t f32_to_u32_sat(float x) {  // Rust `as u32`
+    if (!(x == x) || x <= 0.0f) return 0u;
+    if (x >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)x;
+}
+
+// Perlin::noise + perlin_interp, texture/noise.rs:41-89,109-140
+V4R_DEV float perlin_noise(const float4 *vec, const uint8_t *perm, V3 p) {
+    float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
+    float u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    uint32_t i = (uint32_t)f32_to_i32_sat(fx), j = (uint32_t)f32_to_i32_sat(fy), k = (uint32_t)f32_to_i32_sat(fz);
+    float uu = u * u * (3.0f - u * 2.0f);
+    float vv = v * v * (3.0f - v * 2.0f);
+    float ww = w * w * (3.0f - w * 2.0f);
+    float accum = 0.0f;
+#pragma unroll
+    for (int di = 0; di < 2; ++di)
+#pragma unroll
+        for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+            for (int dk = 0; dk < 2; ++dk) {
+                uint32_t idx = perm[(i + di) & 255u] ^ perm[256 + ((j + dj) & 255u)] ^ perm[512 + ((k + dk) & 255u)];
+                float4 c = vec[idx];
+                float d = c.x * (u - (float)di) + c.y * (v - (float)dj) + c.z * (w - (float)dk);
+                accum += (di ? uu : 1.0f - uu) * (dj ? vv : 1.0f - vv) * (dk ? ww : 1.0f - ww) * d;
+            }
+    return accum;
+}
+
+// Texture::value for the four texture kinds; `uvf` computes (u,v) on demand.
+template <class UV>
+V4R_DEV V3 texture_value(const SceneDev &S, uint32_t tex, V3 p, UV uvf, uint32_t &texel_fetches) {
+    for (int guard = 0; guard < 64; ++guard) {
+        const uint32_t *t = S.textures + 8 * (size_t)tex;
+        uint32_t kind = t[0];
+        if (kind == V4R_TEX_SOLID)  // texture/solid_color.rs:25-27
+            return v3(__uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3]));
+        if (kind == V4R_TEX_CHECKER) {  // texture/checker.rs:31-38
+            float dens = __uint_as_float(t[4]);
+            float sines = sinf(dens * p.x) * sinf(dens * p.y) * sinf(dens * p.z);
+            tex = sines > 0.0f ? t[6] : t[5];  // even : odd
+            continue;
+        }
+        if (kind == V4R_TEX_IMAGE) {  // texture/image.rs:25-73
+            float u, v;
+            uvf(u, v);
+            uint4 img = S.images[t[5]];
+            float cu = u < 0.0f ? 0.0f : (u > 1.0f ? 1.0f : u);
+            float cv = 1.0f - (v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v));
+            uint32_t i = f32_to_u32_sat((float)img.y * cu);
+            if (!(i < img.y)) i = img.y - 1;
+            uint32_t j = f32_to_u32_sat((float)img.z * cv);
+            if (!(j < img.z)) j = img.z - 1;
+            uint32_t px = S.texels[(size_t)img.x + (size_t)j * img.y + i];
+            texel_fetches++;
+            return v3((float)(px & 255u) / 255.0f, (float)((px >> 8) & 255u) / 255.0f, (float)((px >> 16) & 255u) / 255.0f);
+        }
+        if (kind == V4R_TEX_NOISE) {  // texture/noise.rs:91-107,165-170
+            float scale = __uint_as_float(t[4]);
+            uint32_t depth = t[6];
+            const float4 *vec = S.perlin_vec + 256 * (size_t)t[5];
+            const uint8_t *perm = S.perlin_perm + 768 * (size_t)t[5];
+            V3 q = p * scale;
+            float accum = 0.0f, weight = 1.0f;
+            for (uint32_t dpt = 0; dpt < depth; ++dpt) {
+                accum += weight * perlin_noise(vec, perm, q);
+                weight *= 0.5f;
+                q = q * 2.0f;
+            }
+            float g = fabsf(accum);
+            return v3(g, g, g);
+        }
+        break;
+    }
+    return v3(0, 0, 0);
+}
+
+// ---- pdfs ---------------------------------------------------------------------------------------
+// Rotation3::face_towards(dir, up): columns x = normalize(up x z), y = normalize(z x x), z = normalize(dir)
+struct Rot {
+    V3 x, y, z;
+};
+V4R_DEV Rot face_towards(V3 dir, V3 up) {
+    Rot r;
+    r.z = normalize(dir);
+    r.x = normalize(cross(up, r.z));
+    r.y = normalize(cross(r.z, r.x));
+    return r;
+}
+V4R_DEV V3 rot_apply(const Rot &r, V3 v) { return r.x * v.x + r.y * v.y + r.z * v.z; }
+V4R_DEV V3 pick_up(float x_component) { return fabsf(x_component) > 0.9f ? v3(0, 1, 0) : v3(1, 0, 0); }
+
+// CosinePdf::value / generate, pdf/cosine.rs:32-47
+V4R_DEV float cosine_value(V3 normal, V3 dir) {
+    float c = dot(dir, normal);
+    return c > 0.0f ? c * FRAC_1_PI : 0.0f;
+}
+V4R_DEV V3 cosine_generate(V3 normal, float r1, float r2) {
+    Rot rot = face_towards(normal, pick_up(normal.x));
+    float z = sqrtf(1.0f - r2);
+    float phi = TWO_PI * r1;
+    float sq = sqrtf(r2);
+    float s, c;
+    sincosf(phi, &s, &c);
+    return rot_apply(rot, v3(c * sq, s * sq, z));
+}
+
+// random_to_sphere, random.rs:27-39
+V4R_DEV V3 random_to_sphere(float radius, float distance_squared, float u_phi, float r2) {
+    float phi = TWO_PI * u_phi;
+    float z = 1.0f + r2 * (sqrtf(1.0f - radius * radius / distance_squared) - 1.0f);
+    float xy = sqrtf(1.0f - z * z);
+    float s, c;
+    sincosf(phi, &s, &c);
+    return v3(c * xy, s * xy, z);
+}
+
+// Samplable::value of one light primitive: sphere.rs:100-131, aa_rect.rs:151-180,
+// triangle.rs:103-132, wrapped by TransformHittable::value (transform.rs:103-116, no Jacobian).
+// Without V4R_FLAG_BOUNDED_LIGHT_PDF a rectangle / triangle yields the un-clipped plane density,
+// which is what a SIMD lane of the reference gets whenever any lane of its packet hits the light.
+V4R_DEV float light_value(const SceneDev &S, uint32_t prim_index, V3 origin, V3 dir) {
+    Prim pr = load_prim(S.prims, prim_index);
+    uint32_t xf = pr.xform();
+    if (xf != V4R_NO_XFORM) {
+        const float *inv = S.xforms + 24 * (size_t)xf + 12;
+        origin = mat_mul(inv, origin) + v3(inv[9], inv[10], inv[11]);
+        dir = normalize(mat_mul(inv, dir));
+    }
+    bool bounded = S.flags & V4R_FLAG_BOUNDED_LIGHT_PDF;
+    uint32_t kind = pr.type() & V4R_PRIM_TYPE_MASK;
+    if (kind == V4R_PRIM_SPHERE) {
+        float t;
+        if (!sphere_t(pr, origin, dir, EPSILON, V4R_INF, t)) return 0.0f;
+        float radius = pr.a.w;
+        float cos_theta_max = sqrtf(1.0f - radius * radius / norm2(v3(pr.a.x, pr.a.y, pr.a.z) - origin));
+        float solid_angle = TWO_PI * (1.0f - cos_theta_max);
+        return solid_angle > 0.0f ? 1.0f / solid_angle : V4R_INF;
+    }
+    if (kind == V4R_PRIM_TRIANGLE) {
+        float t, u, v, det;
+        bool hit = tri_t(pr, origin, dir, EPSILON, V4R_INF, t, u, v, det);
+        if (bounded && !hit) return 0.0f;
+        const float4 *tp = S.tri + 4 * (size_t)pr.aux();
+        float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+        float w = 1.0f - u - v;
+        V3 normal = normalize(v3(q0.x, q0.y, q0.z) * w + v3(q0.w, q1.x, q1.y) * u + v3(q1.z, q1.w, q2.x) * v);
+        V3 e12 = v3(pr.a.w, pr.b.x, pr.b.y), e13 = v3(pr.b.z, pr.b.w, pr.c.x);
+        float area = norm(cross(e12, e13)) * 0.5f;
+        float cosine = fabsf(dot(dir, normal));
+        return cosine > 0.0f ? (t * t) / (cosine * area) : V4R_INF;
+    }
+    if (kind <= V4R_PRIM_ZX_RECT) {
+        float t;
+        bool hit = rect_t(pr, origin, dir, EPSILON, V4R_INF, t);
+        if (bounded && !hit) return 0.0f;
+        int ia, ib, ik;
+        rect_axes(pr.type(), ia, ib, ik);
+        float area = (pr.a.y - pr.a.x) * (pr.a.w - pr.a.z);
+        float cosine = fabsf(comp(dir, ik));
+        return cosine > 0.0f ? (t * t) / (cosine * area) : V4R_INF;
+    }
+    return 0.0f;
+}
+
+// Samplable::generate: sphere.rs:132-144, aa_rect.rs:182-185 (+ rect_random!, :54-76),
+// triangle.rs:134-146, wrapped by TransformHittable::generate (transform.rs:118-124).
+V4R_DEV V3 light_generate(const SceneDev &S, uint32_t prim_index, V3 origin, float u0, float u1) {
+    Prim pr = load_prim(S.prims, prim_index);
+    uint32_t xf = pr.xform();
+    const float *x = nullptr;
+    if (xf != V4R_NO_XFORM) {
+        x = S.xforms + 24 * (size_t)xf;
+        origin = mat_mul(x + 12, origin) + v3(x[21], x[22], x[23]);
+    }
+    V3 dir;
+    uint32_t kind = pr.type() & V4R_PRIM_TYPE_MASK;
+    if (kind == V4R_PRIM_SPHERE) {
+        V3 direction = v3(pr.a.x, pr.a.y, pr.a.z) - origin;
+        Rot rot = face_towards(direction, pick_up(normalize(direction).x));
+        dir = normalize(rot_apply(rot, random_to_sphere(pr.a.w, norm2(direction), u0, u1)));
+    } else if (kind == V4R_PRIM_TRIANGLE) {
+        float lo = EPSILON, hi = 1.0f - EPSILON;
+        float px = lo + (hi - lo) * u0, py = lo + (hi - lo) * u1;
+        if (px + py > 1.0f) {
+            px = 1.0f - EPSILON - px;
+            py = 1.0f - EPSILON - py;
+        }
+        V3 v0 = v3(pr.a.x, pr.a.y, pr.a.z), e12 = v3(pr.a.w, pr.b.x, pr.b.y), e13 = v3(pr.b.z, pr.b.w, pr.c.x);
+        dir = normalize(v0 + e12 * px + e13 * py - origin);
+    } else if (kind == V4R_PRIM_XY_RECT) {
+        float a = pr.a.x + (pr.a.y - pr.a.x) * u0, b = pr.a.z + (pr.a.w - pr.a.z) * u1;
+        dir = normalize(v3(a, b, pr.b.x) - origin);
+    } else if (kind == V4R_PRIM_YZ_RECT) {
+        float a = pr.a.x + (pr.a.y - pr.a.x) * u0, b = pr.a.z + (pr.a.w - pr.a.z) * u1;
+        dir = normalize(v3(pr.b.x, a, b) - origin);
+    } else if (kind == V4R_PRIM_ZX_RECT) {  // the x coordinate (b range) is drawn first, aa_rect.rs:69-75
+        float b = pr.a.z + (pr.a.w - pr.a.z) * u0, a = pr.a.x + (pr.a.y - pr.a.x) * u1;
+        dir = normalize(v3(b, pr.b.x, a) - origin);
+    } else {
+        dir = v3(1, 0, 0);
+    }
+    if (x) dir = normalize(mat_mul(x, dir));
+    return dir;
+}
+
+// HittableGroup::value over the light list, hittables/group.rs:76-89
+V4R_DEV float lights_value(const SceneDev &S, V3 origin, V3 dir) {
+    float weight = 1.0f / (float)S.n_lights;
+    float sum = 0.0f;
+    for (uint32_t i = 0; i < S.n_lights; ++i) sum += weight * light_value(S, S.lights[i], origin, dir);
+    return sum;
+}
+
+// ---- materials ----------------------------------------------------------------------------------
+V4R_DEV V3 reflect(V3 v, V3 n) { return v - n * (dot(v, n) * 2.0f); }  // material/mod.rs:47-52
+V4R_DEV V3 refract(V3 uv, V3 n, float ratio) {                        // material/mod.rs:54-63
+    float cos_theta = -dot(uv, n);
+    V3 perp = (uv + n * cos_theta) * ratio;
+    V3 parallel = n * (-sqrtf(1.0f - norm2(perp)));
+    return perp + parallel;
+}
+V4R_DEV float reflectance(float cosine, float ref_idx) {  // material/dielectric.rs:23-27
+    float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
+    r0 = r0 * r0;
+    float x = 1.0f - cosine;
+    float x2 = x * x;
+    return r0 + (1.0f - r0) * (x2 * x2 * x);
+}
+
+}  // namespace v4r

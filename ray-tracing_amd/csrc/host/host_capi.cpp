@@ -1,0 +1,422 @@
+// extern "C" surface of the host-side scene pipeline (see include/v4ray_host.h).
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <stdexcept>
+#include <string>
+
+#include "scene.hpp"
+#include "v4ray_host.h"
+
+using namespace v4ray;
+
+struct v4rh_scene {
+    std::unique_ptr<Scene> scene;
+    RendererParam renderer;
+    CameraParam camera;
+};
+
+struct v4rh_shape {
+    std::vector<Hittable> items;
+};
+
+namespace {
+thread_local std::string g_error;
+
+int fail(const std::exception &e) {
+    g_error = e.what();
+    return -1;
+}
+int fail(const char *msg) {
+    g_error = msg;
+    return -1;
+}
+
+template <class F>
+int guarded(F &&f) {
+    try {
+        return f();
+    } catch (const std::exception &e) {
+        return fail(e);
+    } catch (...) {
+        return fail("unknown error");
+    }
+}
+
+template <class F>
+v4rh_shape *guarded_shape(F &&f) {
+    try {
+        auto *s = new v4rh_shape();
+        s->items = f();
+        return s;
+    } catch (const std::exception &e) {
+        fail(e);
+    } catch (...) {
+        fail("unknown error");
+    }
+    return nullptr;
+}
+}  // namespace
+
+extern "C" {
+
+const char *v4rh_last_error(void) { return g_error.c_str(); }
+
+int v4rh_scene_new(const float background[3], const float environment[3], v4rh_scene **out) {
+    return guarded([&] {
+        if (!out || !background) throw std::runtime_error("v4rh_scene_new: NULL argument");
+        auto *s = new v4rh_scene();
+        Vec3 env = environment ? Vec3(environment) : Vec3(0, 0, 0);
+        s->scene = std::make_unique<Scene>(Vec3(background), env);
+        *out = s;
+        return 0;
+    });
+}
+
+void v4rh_scene_free(v4rh_scene *s) { delete s; }
+
+static int adopt(LoadedScene &&ls, v4rh_scene **out) {
+    auto *s = new v4rh_scene();
+    s->scene = std::move(ls.scene);
+    s->renderer = ls.renderer;
+    s->camera = ls.camera;
+    *out = s;
+    return 0;
+}
+
+int v4rh_scene_load_json_file(const char *path, uint64_t perlin_seed, v4rh_scene **out) {
+    return guarded([&] {
+        if (!path || !out) throw std::runtime_error("v4rh_scene_load_json_file: NULL argument");
+        return adopt(load_scene_file(path, perlin_seed), out);
+    });
+}
+
+int v4rh_scene_load_json_text(const char *text, const char *base_dir, uint64_t perlin_seed, v4rh_scene **out) {
+    return guarded([&] {
+        if (!text || !out) throw std::runtime_error("v4rh_scene_load_json_text: NULL argument");
+        return adopt(load_scene_json(text, base_dir ? base_dir : "", perlin_seed), out);
+    });
+}
+
+int v4rh_texture_solid_color(v4rh_scene *s, const float color[3]) {
+    return guarded([&] { return (int)s->scene->add_solid_color(Vec3(color)); });
+}
+int v4rh_texture_checker(v4rh_scene *s, int odd, int even, float density) {
+    return guarded([&] {
+        if (odd < 0 || even < 0) throw std::runtime_error("checker: negative texture id");
+        return (int)s->scene->add_checker((uint32_t)odd, (uint32_t)even, density);
+    });
+}
+int v4rh_texture_image(v4rh_scene *s, const uint8_t *rgb, uint32_t width, uint32_t height) {
+    return guarded([&] {
+        if (!rgb) throw std::runtime_error("image: NULL pixels");
+        Image img;
+        img.width = width;
+        img.height = height;
+        img.rgb.assign(rgb, rgb + (size_t)width * height * 3);
+        return (int)s->scene->add_image(std::move(img));
+    });
+}
+int v4rh_texture_image_file(v4rh_scene *s, const char *path) {
+    return guarded([&] { return (int)s->scene->add_image(load_image(path)); });
+}
+int v4rh_texture_noise(v4rh_scene *s, float scale, uint32_t depth, uint64_t seed) {
+    return guarded([&] { return (int)s->scene->add_noise(scale, depth, seed); });
+}
+int v4rh_material_lambertian(v4rh_scene *s, int texture) {
+    return guarded([&] {
+        if (texture < 0) throw std::runtime_error("lambertian: negative texture id");
+        return (int)s->scene->add_lambertian((uint32_t)texture);
+    });
+}
+int v4rh_material_metal(v4rh_scene *s, const float albedo[3], float fuzz) {
+    return guarded([&] { return (int)s->scene->add_metal(Vec3(albedo), fuzz); });
+}
+int v4rh_material_dielectric(v4rh_scene *s, float ir) {
+    return guarded([&] { return (int)s->scene->add_dielectric(ir); });
+}
+int v4rh_material_diffuse_light(v4rh_scene *s, int texture) {
+    return guarded([&] {
+        if (texture < 0) throw std::runtime_error("diffuse light: negative texture id");
+        return (int)s->scene->add_diffuse_light((uint32_t)texture);
+    });
+}
+int v4rh_material_isotropic(v4rh_scene *s, int texture) {
+    return guarded([&] {
+        if (texture < 0) throw std::runtime_error("isotropic: negative texture id");
+        return (int)s->scene->add_isotropic((uint32_t)texture);
+    });
+}
+
+v4rh_shape *v4rh_shape_sphere(const float center[3], float radius) {
+    return guarded_shape([&] { return std::vector<Hittable>{make_sphere(Vec3(center), radius)}; });
+}
+v4rh_shape *v4rh_shape_rect(uint32_t rect_type, float a0, float a1, float b0, float b1, float k, int positive) {
+    return guarded_shape([&] { return std::vector<Hittable>{make_rect(rect_type, a0, a1, b0, b1, k, positive != 0)}; });
+}
+v4rh_shape *v4rh_shape_triangle(const float vertices[9], const float *normals9, const float *uvs6) {
+    return guarded_shape([&] {
+        Vec3 v[3], n[3];
+        float uv[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+        for (int k = 0; k < 3; ++k) v[k] = Vec3(vertices + 3 * k);
+        if (normals9) {
+            for (int k = 0; k < 3; ++k) n[k] = Vec3(normals9 + 3 * k);
+        } else {  // json.rs:580-586
+            Vec3 nrm = normalize(cross(v[1] - v[0], v[2] - v[1]));
+            n[0] = n[1] = n[2] = nrm;
+        }
+        if (uvs6)
+            for (int k = 0; k < 3; ++k) {
+                uv[k][0] = uvs6[2 * k];
+                uv[k][1] = uvs6[2 * k + 1];
+            }
+        return std::vector<Hittable>{make_triangle(v, n, uv)};
+    });
+}
+v4rh_shape *v4rh_shape_cuboid(const float p0[3], const float p1[3]) {
+    return guarded_shape([&] { return make_cuboid(Vec3(p0), Vec3(p1)); });
+}
+v4rh_shape *v4rh_shape_mesh_file(const char *path, int model, int subdivide_levels) {
+    return guarded_shape([&] {
+        std::vector<ObjMesh> models = load_obj(path);
+        if (models.empty()) throw std::runtime_error("obj file holds no model");
+        size_t idx = model < 0 ? 0 : (size_t)model;
+        if (idx >= models.size()) throw std::runtime_error("model index out of range");
+        if (subdivide_levels > 0) return mesh_to_triangles(subdivide(models[idx], subdivide_levels));
+        return mesh_to_triangles(models[idx]);
+    });
+}
+v4rh_shape *v4rh_shape_constant_medium(const v4rh_shape *boundary, float density) {
+    return guarded_shape([&] {
+        if (!boundary) throw std::runtime_error("constant medium: NULL boundary");
+        return std::vector<Hittable>{make_medium(boundary->items, density)};
+    });
+}
+int v4rh_shape_transform(v4rh_shape *shape, const float matrix9[9], const float translate[3]) {
+    return guarded([&] {
+        if (!shape) throw std::runtime_error("v4rh_shape_transform: NULL shape");
+        Affine a;
+        if (matrix9) std::memcpy(a.m, matrix9, sizeof a.m);
+        if (translate) std::memcpy(a.t, translate, sizeof a.t);
+        for (auto &h : shape->items) h = with_transform(std::move(h), a);
+        return 0;
+    });
+}
+int v4rh_shape_count(const v4rh_shape *shape) { return shape ? (int)shape->items.size() : 0; }
+void v4rh_shape_free(v4rh_shape *shape) { delete shape; }
+
+int v4rh_scene_add(v4rh_scene *s, const v4rh_shape *shape, int material, int important) {
+    return guarded([&] {
+        if (!s || !shape) throw std::runtime_error("v4rh_scene_add: NULL argument");
+        if (material < 0) throw std::runtime_error("v4rh_scene_add: negative material id");
+        for (auto &h : shape->items) {
+            if (important) {
+                if (h.samplable) s->scene->add_important(h, (uint32_t)material);
+                else fprintf(stderr, "importance sampling on unsupported shape!\n");  // json.rs:692
+            } else {
+                s->scene->add(h, (uint32_t)material);
+            }
+        }
+        return 0;
+    });
+}
+int v4rh_scene_len(const v4rh_scene *s) { return s ? (int)s->scene->len() : 0; }
+
+int v4rh_scene_set_renderer(v4rh_scene *s, const v4rh_renderer_param *p) {
+    return guarded([&] {
+        if (!s || !p) throw std::runtime_error("v4rh_scene_set_renderer: NULL argument");
+        RendererParam r;
+        r.width = p->width;
+        r.height = p->height;
+        r.has_max_depth = p->max_depth >= 0;
+        if (r.has_max_depth) r.max_depth = (uint32_t)p->max_depth;
+        r.has_antialias = p->antialias >= 0;
+        r.antialias = p->antialias != 0;
+        s->renderer = r;
+        return 0;
+    });
+}
+int v4rh_scene_get_renderer(const v4rh_scene *s, v4rh_renderer_param *p) {
+    if (!s || !p) return fail("v4rh_scene_get_renderer: NULL argument");
+    p->width = s->renderer.width;
+    p->height = s->renderer.height;
+    p->max_depth = s->renderer.has_max_depth ? (int32_t)s->renderer.max_depth : -1;
+    p->antialias = s->renderer.has_antialias ? (s->renderer.antialias ? 1 : 0) : -1;
+    return 0;
+}
+int v4rh_scene_set_camera(v4rh_scene *s, const v4rh_camera_param *p) {
+    return guarded([&] {
+        if (!s || !p) throw std::runtime_error("v4rh_scene_set_camera: NULL argument");
+        CameraParam c;
+        c.look_from = Vec3(p->look_from);
+        c.look_at = Vec3(p->look_at);
+        c.vfov = p->vfov;
+        c.has_up = p->has & V4RH_CAM_UP;
+        c.up = Vec3(p->up);
+        c.has_aspect = p->has & V4RH_CAM_ASPECT;
+        c.aspect_ratio = p->aspect_ratio;
+        c.has_aperture = p->has & V4RH_CAM_APERTURE;
+        c.aperture = p->aperture;
+        c.has_focus = p->has & V4RH_CAM_FOCUS;
+        c.focus_dist = p->focus_dist;
+        c.has_time0 = p->has & V4RH_CAM_TIME0;
+        c.time0 = p->time0;
+        c.has_time1 = p->has & V4RH_CAM_TIME1;
+        c.time1 = p->time1;
+        s->camera = c;
+        return 0;
+    });
+}
+int v4rh_scene_get_camera(const v4rh_scene *s, v4rh_camera_param *p) {
+    if (!s || !p) return fail("v4rh_scene_get_camera: NULL argument");
+    const CameraParam &c = s->camera;
+    std::memset(p, 0, sizeof *p);
+    c.look_from.store(p->look_from);
+    c.look_at.store(p->look_at);
+    p->vfov = c.vfov;
+    c.up.store(p->up);
+    p->aspect_ratio = c.aspect_ratio;
+    p->aperture = c.aperture;
+    p->focus_dist = c.focus_dist;
+    p->time0 = c.time0;
+    p->time1 = c.time1;
+    p->has = (c.has_up ? V4RH_CAM_UP : 0) | (c.has_aspect ? V4RH_CAM_ASPECT : 0) | (c.has_aperture ? V4RH_CAM_APERTURE : 0) |
+             (c.has_focus ? V4RH_CAM_FOCUS : 0) | (c.has_time0 ? V4RH_CAM_TIME0 : 0) | (c.has_time1 ? V4RH_CAM_TIME1 : 0);
+    return 0;
+}
+int v4rh_scene_set_options(v4rh_scene *s, int pretransform_triangles, uint32_t flags) {
+    if (!s) return fail("v4rh_scene_set_options: NULL scene");
+    s->scene->set_pretransform_triangles(pretransform_triangles != 0);
+    s->scene->set_flags(flags);
+    return 0;
+}
+
+int v4rh_scene_flatten(v4rh_scene *s, const v4r_scene_desc **out) {
+    return guarded([&] {
+        if (!s || !out) throw std::runtime_error("v4rh_scene_flatten: NULL argument");
+        *out = &s->scene->flatten(s->renderer, s->camera);
+        return 0;
+    });
+}
+
+int v4rh_bvh_build(const float *boxes, uint32_t n, v4rh_bvh_node *nodes, uint32_t *n_nodes) {
+    return guarded([&] {
+        if ((!boxes && n) || !n_nodes) throw std::runtime_error("v4rh_bvh_build: NULL argument");
+        std::vector<AABB> shapes(n);
+        for (uint32_t i = 0; i < n; ++i) shapes[i] = AABB::with_bounds(Vec3(boxes + 6 * i), Vec3(boxes + 6 * i + 3));
+        BVH bvh = BVH::build(shapes);
+        *n_nodes = (uint32_t)bvh.nodes.size();
+        if (nodes)
+            for (size_t i = 0; i < bvh.nodes.size(); ++i) {
+                const BVHNode &b = bvh.nodes[i];
+                v4rh_bvh_node &o = nodes[i];
+                std::memset(&o, 0, sizeof o);
+                o.parent_index = b.parent_index;
+                o.depth = b.depth;
+                o.leaf = b.leaf ? 1u : 0u;
+                o.shape_index = b.shape_index;
+                if (!b.leaf)
+                    for (int c = 0; c < 2; ++c) {
+                        o.children_index[c] = b.children_index[c];
+                        b.children_aabb[c].min.store(o.children_aabb[c]);
+                        b.children_aabb[c].max.store(o.children_aabb[c] + 3);
+                    }
+            }
+        return 0;
+    });
+}
+
+int v4rh_scene_bounding_box(const v4rh_scene *s, uint32_t index, float out6[6]) {
+    return guarded([&] {
+        if (!s || !out6) throw std::runtime_error("v4rh_scene_bounding_box: NULL argument");
+        if (index >= s->scene->len()) throw std::runtime_error("v4rh_scene_bounding_box: index out of range");
+        AABB b = s->scene->hittables()[index].bounding_box();
+        b.min.store(out6);
+        b.max.store(out6 + 3);
+        return 0;
+    });
+}
+
+int v4rh_image_load(const char *path, uint32_t *width, uint32_t *height, uint8_t *rgb, uint64_t capacity) {
+    return guarded([&] {
+        if (!path || !width || !height) throw std::runtime_error("v4rh_image_load: NULL argument");
+        Image img = load_image(path);
+        *width = img.width;
+        *height = img.height;
+        if (rgb) {
+            if (capacity < img.rgb.size()) throw std::runtime_error("v4rh_image_load: buffer too small");
+            std::memcpy(rgb, img.rgb.data(), img.rgb.size());
+        }
+        return 0;
+    });
+}
+
+// RenderResult::get_raw, src/renderer.rs:378-402: scale by 1/n, sqrt, scale by 256, clamp to
+// [0.5, 255.5], truncate to u8; NaN -> 0.
+int v4rh_tonemap_u8(const float *sums, uint64_t n_floats, uint32_t n_passes, uint8_t *out) {
+    if (!sums || !out) return fail("v4rh_tonemap_u8: NULL argument");
+    if (n_passes == 0) return fail("v4rh_tonemap_u8: no passes accumulated");
+    float scale1 = 1.0f / (float)n_passes;
+    for (uint64_t i = 0; i < n_floats; ++i) {
+        float v = std::sqrt(sums[i] * scale1) * 256.0f;
+        if (v != v) {
+            out[i] = 0;
+            continue;
+        }
+        v = v < 0.5f ? 0.5f : (v > 255.5f ? 255.5f : v);
+        out[i] = (uint8_t)v;
+    }
+    return 0;
+}
+
+int v4rh_write_image(const char *path, const uint8_t *rgb, uint32_t width, uint32_t height) {
+    return guarded([&] {
+        if (!path || !rgb) throw std::runtime_error("v4rh_write_image: NULL argument");
+        std::string p(path);
+        std::ofstream f(p, std::ios::binary);
+        if (!f) throw std::runtime_error("cannot open output image: " + p);
+        bool ppm = p.size() >= 4 && p.compare(p.size() - 4, 4, ".ppm") == 0;
+        if (ppm) {
+            f << "P6\n" << width << " " << height << "\n255\n";
+            f.write((const char *)rgb, (std::streamsize)((size_t)width * height * 3));
+        } else {  // 24-bit BMP, bottom-up rows, BGR, rows padded to 4 bytes
+            uint32_t row = (width * 3 + 3) & ~3u;
+            uint32_t data_size = row * height, file_size = 54 + data_size;
+            uint8_t hdr[54] = {0};
+            hdr[0] = 'B';
+            hdr[1] = 'M';
+            auto put32 = [&](int off, uint32_t v) {
+                hdr[off] = (uint8_t)v;
+                hdr[off + 1] = (uint8_t)(v >> 8);
+                hdr[off + 2] = (uint8_t)(v >> 16);
+                hdr[off + 3] = (uint8_t)(v >> 24);
+            };
+            put32(2, file_size);
+            put32(10, 54);
+            put32(14, 40);
+            put32(18, width);
+            put32(22, height);
+            hdr[26] = 1;
+            hdr[28] = 24;
+            put32(34, data_size);
+            put32(38, 2835);
+            put32(42, 2835);
+            f.write((const char *)hdr, 54);
+            std::vector<uint8_t> line(row, 0);
+            for (uint32_t y = 0; y < height; ++y) {
+                const uint8_t *src = rgb + (size_t)(height - 1 - y) * width * 3;
+                for (uint32_t x = 0; x < width; ++x) {
+                    line[3 * x] = src[3 * x + 2];
+                    line[3 * x + 1] = src[3 * x + 1];
+                    line[3 * x + 2] = src[3 * x];
+                }
+                f.write((const char *)line.data(), row);
+            }
+        }
+        if (!f) throw std::runtime_error("failed writing output image: " + p);
+        return 0;
+    });
+}
+
+}  // extern "C"
