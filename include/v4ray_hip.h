@@ -258,6 +258,11 @@ int v4r_trace_rays(v4r_renderer *r, uint32_t n, const float *host_origin, const 
 int v4r_stats_enable(v4r_renderer *r, int on);
 int v4r_stats_read(v4r_renderer *r, v4r_stats *out, int reset);
 
+/* Time every launch of the traversal kernel with a pair of HIP events recorded on the renderer's
+ * stream, and read the accumulated device time and launch count (synchronises first). */
+int v4r_profile_enable(v4r_renderer *r, int on);
+int v4r_profile_read(v4r_renderer *r, double *trace_ms, uint64_t *trace_launches, int reset);
+
 /* Block until every queued pass has finished. */
 int v4r_synchronize(v4r_renderer *r);
 

@@ -54,12 +54,28 @@ struct Queues {
 
 V4R_DEV uint32_t lane_id() { return threadIdx.x & 63u; }
 
-// Take the next 64 queue entries for this wave.
-V4R_DEV uint32_t wave_fetch(uint32_t *cursor) {
-    uint32_t base = 0;
-    if (lane_id() == 0) base = atomicAdd(cursor, 64u);
-    return __builtin_amdgcn_readfirstlane(base);
-}
+// Work distribution over a queue: every wave of the grid first takes the 64 entries at its own
+// position (no atomic, so a launch over an empty or short queue costs nothing), then pulls further
+// 64-entry chunks from a shared cursor, which balances waves whose rays take unequal time.
+struct WaveFetch {
+    uint32_t *cursor;
+    uint32_t first, dynamic_base;
+    bool started;
+    __device__ __forceinline__ WaveFetch(uint32_t *cursor_) : cursor(cursor_), started(false) {
+        uint32_t waves_per_block = blockDim.x >> 6;
+        first = (blockIdx.x * waves_per_block + (threadIdx.x >> 6)) * 64u;
+        dynamic_base = gridDim.x * waves_per_block * 64u;
+    }
+    __device__ __forceinline__ uint32_t next() {
+        if (!started) {
+            started = true;
+            return first;
+        }
+        uint32_t base = 0;
+        if (lane_id() == 0) base = atomicAdd(cursor, 64u);
+        return dynamic_base + __builtin_amdgcn_readfirstlane(base);
+    }
+};
 
 // Reserve one output slot per lane with `flag` set: wave ballot, one atomic per wave, prefix rank.
 V4R_DEV uint32_t wave_push(bool flag, uint32_t *counter) {
@@ -167,8 +183,9 @@ __global__ __launch_bounds__(BLOCK) void k_trace(SceneDev S, Queues Q, uint32_t 
     float4 *const *rq = Q.ray[seg & 1u];
     TraceCounters cnt;
     uint32_t n_traced = 0;
+    WaveFetch fetch(&ctr->trace_cursor);
     while (true) {
-        uint32_t base = wave_fetch(&ctr->trace_cursor);
+        uint32_t base = fetch.next();
         if (base >= n_in) break;
         uint32_t i = base + lane_id();
         bool valid = i < n_in;
@@ -221,8 +238,9 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, Queues Q, uint32_t 
     float4 *const *out = Q.ray[(seg + 1u) & 1u];
     const bool last = seg + 1u >= S.max_depth;
     uint32_t n_shaded = 0, texel_fetches = 0;
+    WaveFetch fetch(&ctr->shade_cursor[CLS]);
     while (true) {
-        uint32_t base = wave_fetch(&ctr->shade_cursor[CLS]);
+        uint32_t base = fetch.next();
         if (base >= n_in) break;
         uint32_t i = base + lane_id();
         bool valid = i < n_in;
@@ -426,6 +444,12 @@ struct v4r_renderer {
     uint32_t npix = 0, n_passes = 0, batch_passes = 1;
     uint32_t grid_trace = 0, grid_shade = 0, grid_stream = 0;
     bool counting = false;
+    // HIP-event timing of the k_trace launches (v4r_profile_*)
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;  // pairs: start, stop
+    size_t ev_used = 0;
+    double trace_ms = 0.0;
+    uint64_t trace_launches = 0;
     bool has_class[CLS_COUNT] = {false, false, false, false, false, false};
     size_t ctr_bytes = 0;
 
@@ -707,8 +731,22 @@ int run_batch(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_t pass
     hipLaunchKernelGGL(k_raygen, dim3(r->grid_stream), dim3(BLOCK), 0, r->stream, r->S, Q, (uint32_t)seed, (uint32_t)(seed >> 32),
                        first_pass, pass_stride, n_paths);
     for (uint32_t seg = 0; seg < r->S.max_depth; ++seg) {
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        if (r->profiling) {
+            if (r->ev_used + 2 > r->ev_pool.size()) {
+                hipEvent_t a, b;
+                HIP_TRY(hipEventCreate(&a));
+                HIP_TRY(hipEventCreate(&b));
+                r->ev_pool.push_back(a);
+                r->ev_pool.push_back(b);
+            }
+            ev0 = r->ev_pool[r->ev_used++];
+            ev1 = r->ev_pool[r->ev_used++];
+            HIP_TRY(hipEventRecord(ev0, r->stream));
+        }
         if (r->counting) hipLaunchKernelGGL(k_trace<true>, dim3(r->grid_trace), dim3(BLOCK), 0, r->stream, r->S, r->Q, seg);
         else hipLaunchKernelGGL(k_trace<false>, dim3(r->grid_trace), dim3(BLOCK), 0, r->stream, r->S, r->Q, seg);
+        if (r->profiling) HIP_TRY(hipEventRecord(ev1, r->stream));
         launch_shade<CLS_LIGHT>(r, seg);
         launch_shade<CLS_LAMBERT>(r, seg);
         launch_shade<CLS_LAMBERT_NOISE>(r, seg);
@@ -757,6 +795,7 @@ void v4r_renderer_destroy(v4r_renderer *r) {
         (void)hipStreamDestroy(r->stream);
     }
     for (void *p : r->allocations) (void)hipFree(p);
+    for (hipEvent_t e : r->ev_pool) (void)hipEventDestroy(e);
     delete r;
 }
 
@@ -882,6 +921,41 @@ int v4r_stats_read(v4r_renderer *r, v4r_stats *out, int reset) {
     out->shaded = h[4];
     out->texel_fetches = h[5];
     if (reset) HIP_TRY(hipMemset(r->Q.stats, 0, 64));
+    return V4R_OK;
+}
+
+// Fold the recorded event pairs into the running totals (the stream must be idle).
+static int profile_collect(v4r_renderer *r) {
+    for (size_t i = 0; i + 1 < r->ev_used; i += 2) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, r->ev_pool[i], r->ev_pool[i + 1]));
+        r->trace_ms += ms;
+        r->trace_launches++;
+    }
+    r->ev_used = 0;
+    return V4R_OK;
+}
+
+int v4r_profile_enable(v4r_renderer *r, int on) {
+    if (!r) return set_error(V4R_E_INVALID, "NULL renderer");
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    if (int rc = profile_collect(r)) return rc;
+    r->profiling = on != 0;
+    return V4R_OK;
+}
+
+int v4r_profile_read(v4r_renderer *r, double *trace_ms, uint64_t *trace_launches, int reset) {
+    if (!r) return set_error(V4R_E_INVALID, "NULL renderer");
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    if (int rc = profile_collect(r)) return rc;
+    if (trace_ms) *trace_ms = r->trace_ms;
+    if (trace_launches) *trace_launches = r->trace_launches;
+    if (reset) {
+        r->trace_ms = 0.0;
+        r->trace_launches = 0;
+    }
     return V4R_OK;
 }
 

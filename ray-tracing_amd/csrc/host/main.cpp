@@ -1,0 +1,136 @@
+// v4ray-hip: command-line renderer with the reference CLI's flags (src/main.rs:18-26:
+// -i/--input scene.json, -o/--output output.bmp) plus --spp, --seed, --device, --batch.
+// Like the reference (src/main.rs:46-79) it renders 1-spp passes progressively, prints
+// "Iter N +Ts" as they complete and rewrites the output image every 5 seconds; unlike it, it
+// stops after --spp passes (the reference runs until Enter is pressed; --spp 0 does the same).
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "v4ray_hip.h"
+#include "v4ray_host.h"
+
+namespace {
+struct Opts {
+    std::string input = "scene.json", output = "output.bmp";
+    uint32_t spp = 64, batch = 8;
+    uint64_t seed = 0x5EED, perlin_seed = 1;
+    int device = 0;
+    bool pretransform = false;
+};
+
+bool parse(int argc, char **argv, Opts &o) {
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        auto need = [&](const char *name) -> const char * {
+            if (i + 1 >= argc) {
+                fprintf(stderr, "missing value for %s\n", name);
+                exit(2);
+            }
+            return argv[++i];
+        };
+        if (a == "-i" || a == "--input") o.input = need("--input");
+        else if (a == "-o" || a == "--output") o.output = need("--output");
+        else if (a == "--spp") o.spp = (uint32_t)std::strtoul(need("--spp"), nullptr, 10);
+        else if (a == "--batch") o.batch = (uint32_t)std::strtoul(need("--batch"), nullptr, 10);
+        else if (a == "--seed") o.seed = std::strtoull(need("--seed"), nullptr, 0);
+        else if (a == "--perlin-seed") o.perlin_seed = std::strtoull(need("--perlin-seed"), nullptr, 0);
+        else if (a == "--device") o.device = std::atoi(need("--device"));
+        else if (a == "--pretransform-triangles") o.pretransform = true;
+        else if (a == "-h" || a == "--help") return false;
+        else {
+            fprintf(stderr, "unknown argument %s\n", a.c_str());
+            return false;
+        }
+    }
+    if (o.batch == 0) o.batch = 1;
+    return true;
+}
+
+int save(v4r_renderer *r, uint32_t n, uint32_t w, uint32_t h, const std::string &path) {
+    std::vector<uint8_t> rgb((size_t)w * h * 3);
+    if (v4r_tonemap_u8(r, n, rgb.data()) != V4R_OK) {
+        fprintf(stderr, "tonemap failed: %s\n", v4r_last_error());
+        return 1;
+    }
+    if (v4rh_write_image(path.c_str(), rgb.data(), w, h) != 0) {
+        fprintf(stderr, "%s\n", v4rh_last_error());
+        return 1;
+    }
+    printf("Iter %u saved\n", n);  // src/main.rs:74
+    return 0;
+}
+}  // namespace
+
+int main(int argc, char **argv) {
+    Opts o;
+    if (!parse(argc, argv, o)) {
+        fprintf(stderr,
+                "usage: v4ray-hip [-i scene.json] [-o output.bmp] [--spp N (0 = until Enter)] [--batch N] [--seed S]\n"
+                "                 [--perlin-seed S] [--device D] [--pretransform-triangles]\n");
+        return 2;
+    }
+    v4rh_scene *scene = nullptr;
+    if (v4rh_scene_load_json_file(o.input.c_str(), o.perlin_seed, &scene) != 0) {
+        fprintf(stderr, "cannot load %s: %s\n", o.input.c_str(), v4rh_last_error());
+        return 1;
+    }
+    v4rh_scene_set_options(scene, o.pretransform ? 1 : 0, 0);
+    const v4r_scene_desc *desc = nullptr;
+    if (v4rh_scene_flatten(scene, &desc) != 0) {
+        fprintf(stderr, "cannot build scene: %s\n", v4rh_last_error());
+        return 1;
+    }
+    v4r_renderer *r = nullptr;
+    if (v4r_renderer_create(desc, o.device, &r) != V4R_OK) {
+        fprintf(stderr, "cannot create renderer: %s\n", v4r_last_error());
+        return 1;
+    }
+    std::atomic<bool> quit{false};
+    std::thread waiter;
+    if (o.spp == 0) {
+        printf("Press enter to exit.\n");  // src/main.rs:81
+        waiter = std::thread([&] {
+            std::string line;
+            std::getline(std::cin, line);
+            quit = true;
+        });
+    }
+    auto start = std::chrono::steady_clock::now();
+    auto last_save = start;
+    uint32_t done = 0;
+    int rc = 0;
+    while (!quit && (o.spp == 0 || done < o.spp)) {
+        uint32_t n = o.spp == 0 ? o.batch : std::min(o.batch, o.spp - done);
+        if (v4r_render(r, o.seed, done, 1, n) != V4R_OK || v4r_synchronize(r) != V4R_OK) {
+            fprintf(stderr, "render failed: %s\n", v4r_last_error());
+            rc = 1;
+            break;
+        }
+        done += n;
+        auto now = std::chrono::steady_clock::now();
+        printf("Iter %u +%llds\n", done, (long long)std::chrono::duration_cast<std::chrono::seconds>(now - start).count());  // src/main.rs:48-52
+        if (now - last_save >= std::chrono::seconds(5)) {  // src/main.rs:68
+            rc |= save(r, done, desc->width, desc->height, o.output);
+            last_save = now;
+        }
+    }
+    if (rc == 0 && done > 0) rc = save(r, done, desc->width, desc->height, o.output);
+    double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
+    if (done > 0)
+        printf("%u passes of %ux%u in %.3f s = %.2f Mpaths/s\n", done, desc->width, desc->height, secs,
+               (double)desc->width * desc->height * done / secs / 1e6);
+    if (waiter.joinable()) {
+        if (!quit) fclose(stdin);
+        waiter.detach();
+    }
+    v4r_renderer_destroy(r);
+    v4rh_scene_free(scene);
+    return rc;
+}

@@ -585,6 +585,15 @@ class Renderer:
                                               prim.ctypes.data_as(C.POINTER(C.c_uint32)), t.ctypes.data_as(fp)))
         return prim, t
 
+    def enable_profile(self, on: bool = True) -> None:
+        check_dev(device_lib().v4r_profile_enable(self._h, int(on)))
+
+    def read_profile(self, reset: bool = False):
+        """(device milliseconds spent in the traversal kernel, number of its launches), from HIP events."""
+        ms, n = C.c_double(), C.c_uint64()
+        check_dev(device_lib().v4r_profile_read(self._h, C.byref(ms), C.byref(n), int(reset)))
+        return float(ms.value), int(n.value)
+
     def enable_stats(self, on: bool = True) -> None:
         check_dev(device_lib().v4r_stats_enable(self._h, int(on)))
 
