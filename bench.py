@@ -87,6 +87,7 @@ def main():
     import torch
     import torch.distributed as dist
     from v4ray_hip import Renderer, scenes
+    from v4ray_hip.distributed import render_split
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
@@ -105,11 +106,14 @@ def main():
     accum = torch.zeros(height, width, 3, dtype=torch.float32, device=f"cuda:{local_rank}")
     r.bind_accumulator(accum.data_ptr())
 
-    def step():
-        r.render_passes(spp, first_pass=rank, pass_stride=world)
+    def render(first, stride, n):
+        r.render_passes(n, first_pass=first, pass_stride=stride)
         if world > 1:
             r.synchronize()  # the renderer runs on its own stream; the collective runs on torch's
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+
+    def step():
+        # rank r: passes r, r+N, ... of an (N * spp)-pass job, then one RCCL reduce of the accumulators
+        render_split(render, accum, spp * world, dst=0)
 
     def fence():
         r.synchronize()

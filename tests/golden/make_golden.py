@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures under tests/golden/ with the CPU oracle.
+
+The reference ships no vectors and cannot be run here, so these fixtures are outputs of this
+repository's oracle (oracle/v4r_oracle.cpp), itself pinned by tests/test_oracle_kat.py.  They guard
+the oracle against regressions and give the GPU tests a fixed target that does not depend on the
+oracle being rebuilt identically.
+
+    python tests/golden/make_golden.py
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "ray-tracing_amd"))
+import oracle  # noqa: E402
+from v4ray_hip import load_image, scenes  # noqa: E402
+
+PRIMARY_SIZE = {"c1": (64, 64), "c2": (96, 54), "c3": (64, 64), "c4": (96, 54), "c5": (96, 54)}
+IMAGE_SIZE = {"c2": (128, 72), "c3": (96, 96), "c4": (128, 72), "c5": (128, 72)}
+IMAGE_SPP = 1024
+SEED = 0x5EED
+
+
+def main():
+    out = {}
+    for name, (w, h) in PRIMARY_SIZE.items():
+        s = scenes.load(name, w, h)
+        d = s.flatten(s.renderer_param, s.camera_param)
+        prim, t = oracle.trace_primary(d)
+        out[f"{name}_primary_prim"] = prim
+        out[f"{name}_primary_t"] = t
+        print(name, "primary", (prim != 0xFFFFFFFF).mean())
+    for name, (w, h) in IMAGE_SIZE.items():
+        s = scenes.load(name, w, h)
+        d = s.flatten(s.renderer_param, s.camera_param)
+        img, stats = oracle.render(d, IMAGE_SPP, seed=SEED)
+        out[f"{name}_image_{IMAGE_SPP}spp"] = (img / IMAGE_SPP).astype(np.float32)
+        img16, _ = oracle.render(d, 16, seed=SEED)
+        out[f"{name}_image_16spp_sum"] = img16
+        print(name, "image mean", img.mean() / IMAGE_SPP, stats)
+    earth = load_image(os.path.join(scenes.ASSETS, "earthmap.jpg"))
+    out["earthmap_sha256"] = np.frombuffer(hashlib.sha256(earth.tobytes()).digest(), dtype=np.uint8)
+    out["earthmap_row_means"] = earth.reshape(512, -1).mean(axis=1).astype(np.float32)
+    s = scenes.load("c5", 32, 18)
+    d = s.flatten(s.renderer_param, s.camera_param)
+    out["perlin_seed1_sha256"] = np.frombuffer(hashlib.sha256(bytes(d.contents.perlin[0])).digest(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "golden.npz"), **out)
+    print("wrote", os.path.join(HERE, "golden.npz"), os.path.getsize(os.path.join(HERE, "golden.npz")), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,97 @@
+"""Golden fixtures (tests/golden/golden.npz, made by tests/golden/make_golden.py with the oracle):
+the oracle must keep reproducing them on the CPU, and the HIP path must match them on the GPU."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from v4ray_hip import load_image, scenes
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = np.load(os.path.join(HERE, "golden", "golden.npz"))
+PRIMARY_SIZE = {"c1": (64, 64), "c2": (96, 54), "c3": (64, 64), "c4": (96, 54), "c5": (96, 54)}
+IMAGE_SIZE = {"c2": (128, 72), "c3": (96, 96), "c4": (128, 72), "c5": (128, 72)}
+MISS = 0xFFFFFFFF
+
+
+def psnr(a, b):
+    """PSNR of the displayed images: sqrt-gamma (renderer.rs:384) of the per-sample mean, clipped to [0,1]."""
+    fa, fb = np.clip(np.sqrt(np.maximum(a, 0)), 0, 1), np.clip(np.sqrt(np.maximum(b, 0)), 0, 1)
+    mse = float(np.mean((fa.astype(np.float64) - fb) ** 2))
+    return 99.0 if mse == 0 else 10 * np.log10(1.0 / mse)
+
+
+def desc_for(name, size):
+    s = scenes.load(name, *size)
+    return s, s.flatten(s.renderer_param, s.camera_param)
+
+
+@pytest.mark.parametrize("name", sorted(PRIMARY_SIZE))
+def test_oracle_reproduces_golden_primary_hits(name):
+    s, d = desc_for(name, PRIMARY_SIZE[name])
+    prim, t = oracle.trace_primary(d)
+    assert np.array_equal(prim, G[f"{name}_primary_prim"])
+    assert np.array_equal(t, G[f"{name}_primary_t"])
+    prim1, t1 = oracle.trace_primary(d, mode=1)     # ordered traversal selects the same hit
+    assert np.array_equal(prim1, prim) and np.array_equal(t1, t)
+
+
+@pytest.mark.parametrize("name", sorted(IMAGE_SIZE))
+def test_oracle_reproduces_golden_16spp_image(name):
+    s, d = desc_for(name, IMAGE_SIZE[name])
+    img, _ = oracle.render(d, 16, seed=0x5EED)
+    assert np.array_equal(img, G[f"{name}_image_16spp_sum"])
+    split = np.zeros_like(img)
+    for rank in range(2):   # pass p is the same wherever it is rendered
+        oracle.render(d, 8, seed=0x5EED, first_pass=rank, pass_stride=2, accum=split)
+    assert np.allclose(split, img, rtol=1e-5, atol=1e-6)
+
+
+def test_decoded_assets_are_stable():
+    earth = load_image(os.path.join(scenes.ASSETS, "earthmap.jpg"))
+    assert hashlib.sha256(earth.tobytes()).digest() == bytes(G["earthmap_sha256"])
+    s, d = desc_for("c5", (32, 18))
+    assert hashlib.sha256(bytes(d.contents.perlin[0])).digest() == bytes(G["perlin_seed1_sha256"])
+
+
+# ---- GPU ------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["c2", "c3", "c4", "c5"])
+def test_device_matches_golden_primary_hits(name):
+    from v4ray_hip import Renderer
+    s = scenes.load(name, *PRIMARY_SIZE[name])
+    r = Renderer(s.renderer_param, s.camera_param, s)
+    prim, t = r.trace_primary()
+    gp, gt = G[f"{name}_primary_prim"], G[f"{name}_primary_t"]
+    same = prim == gp
+    hit = same & (gp != MISS)
+    rel = np.zeros(gp.shape)
+    rel[hit] = np.abs(t[hit].astype(np.float64) - gt[hit]) / np.abs(gt[hit])
+    assert (same & (rel <= 1e-5)).mean() >= 0.9999
+    r.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["c2", "c3", "c4", "c5"])
+def test_device_converged_image_psnr(name):
+    """>= 1024 spp: PSNR >= 40 dB against the oracle's render of the same scene (same random streams), and a
+    render from different streams agrees up to Monte-Carlo noise."""
+    from v4ray_hip import Renderer
+    s = scenes.load(name, *IMAGE_SIZE[name])
+    r = Renderer(s.renderer_param, s.camera_param, s, seed=0x5EED)
+    r.render_passes(1024)
+    img, n = r.read_accumulator()
+    img /= n
+    gold = G[f"{name}_image_1024spp"]
+    p_same = psnr(img, gold)
+    r.clear()
+    r.render_passes(1024, seed=0xC0FFEE)
+    other = r.read_accumulator()[0] / 1024
+    p_other = psnr(other, gold)
+    print(f"{name}: PSNR same streams {p_same:.1f} dB, independent streams {p_other:.1f} dB")
+    assert p_same >= 40.0
+    assert p_other >= 28.0
+    assert abs(other.mean() - gold.mean()) <= 0.01 * gold.mean()
+    r.close()
