@@ -30,6 +30,10 @@ using namespace v4r;
 namespace {
 
 constexpr int BLOCK = 256;
+#ifndef V4R_TRACE_RAYS_PER_THREAD
+#define V4R_TRACE_RAYS_PER_THREAD 4
+#endif
+constexpr int TRACE_RAYS_PER_THREAD = V4R_TRACE_RAYS_PER_THREAD;
 
 // Per-segment queue counters, zeroed once per batch.
 struct SegCtr {
@@ -44,6 +48,7 @@ static_assert(sizeof(SegCtr) == 64, "SegCtr is one 64-byte line");
 struct Queues {
     float4 *ray[2][3];          // [segment parity][column]: {o.xyz,d.x} {d.yz,thr.rg} {thr.b,slot,k0,k1}
     float4 *hit[CLS_COUNT][4];  // the three ray columns + {t, prim, u, v}
+    float4 *hitd;               // {t, prim, u, v} of ray i of the segment being traced (staging for the class queues)
     float4 *rad;                // per path slot: radiance of the finished path
     SegCtr *ctr;                // [max_depth + 1]
     uint2 *spill;               // traversal stack overflow, [entry][global thread]
@@ -53,40 +58,6 @@ struct Queues {
 };
 
 V4R_DEV uint32_t lane_id() { return threadIdx.x & 63u; }
-
-// Work distribution over a queue: every wave of the grid first takes the 64 entries at its own
-// position (no atomic, so a launch over an empty or short queue costs nothing), then pulls further
-// 64-entry chunks from a shared cursor, which balances waves whose rays take unequal time.
-struct WaveFetch {
-    uint32_t *cursor;
-    uint32_t first, dynamic_base;
-    bool started;
-    __device__ __forceinline__ WaveFetch(uint32_t *cursor_) : cursor(cursor_), started(false) {
-        uint32_t waves_per_block = blockDim.x >> 6;
-        first = (blockIdx.x * waves_per_block + (threadIdx.x >> 6)) * 64u;
-        dynamic_base = gridDim.x * waves_per_block * 64u;
-    }
-    __device__ __forceinline__ uint32_t next() {
-        if (!started) {
-            started = true;
-            return first;
-        }
-        uint32_t base = 0;
-        if (lane_id() == 0) base = atomicAdd(cursor, 64u);
-        return dynamic_base + __builtin_amdgcn_readfirstlane(base);
-    }
-};
-
-// Reserve one output slot per lane with `flag` set: wave ballot, one atomic per wave, prefix rank.
-V4R_DEV uint32_t wave_push(bool flag, uint32_t *counter) {
-    unsigned long long mask = __ballot(flag);
-    if (mask == 0ull) return 0;
-    uint32_t base = 0;
-    if (lane_id() == 0) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-    base = __builtin_amdgcn_readfirstlane(base);
-    uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-    return base + rank;
-}
 
 V4R_DEV unsigned long long wave_sum(unsigned long long v) {
 #pragma unroll
@@ -169,9 +140,38 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(SceneDev S, Queues Q, uint32_t
     }
 }
 
-template <bool COUNT>
+// Rays queued for segment `seg`: the camera rays for segment 0, afterwards one ray per hit that the
+// scattering classes of the previous segment shaded (lights never scatter, diffuse_light.rs).
+V4R_DEV uint32_t rays_in(const Queues &Q, uint32_t seg) {
+    if (seg == 0) return Q.ctr[0].ray_count;
+    const SegCtr &prev = Q.ctr[seg - 1u];
+    uint32_t n = 0;
+#pragma unroll
+    for (int k = 0; k < CLS_COUNT; ++k)
+        if (k != CLS_LIGHT) n += prev.hit_count[k];
+    return n;
+}
+// Position of class `cls` inside the ray queue that the shading kernels of segment `seg` fill: the
+// classes are laid out back to back in class order, so every shaded hit knows its slot without an atomic.
+V4R_DEV uint32_t class_base(const Queues &Q, uint32_t seg, int cls) {
+    const SegCtr &c = Q.ctr[seg];
+    uint32_t n = 0;
+#pragma unroll
+    for (int k = 0; k < CLS_COUNT; ++k)
+        if (k != CLS_LIGHT && k < cls) n += c.hit_count[k];
+    return n;
+}
+
+// BVH traversal + closest hit for the rays of one segment.  A workgroup takes RAYS_PER_THREAD*256 rays
+// at a time (the chunk at its own grid position first, then chunks from a shared cursor: one global
+// atomic per chunk), traces them, ranks the hits of the chunk per shading class in LDS (wave64 ballot +
+// mbcnt prefix, one LDS atomic per wave and class), reserves the chunk's slots in each class queue with
+// one global atomic per class, and copies the ray + hit records there.
+template <bool COUNT, int RAYS_PER_THREAD>
 __global__ __launch_bounds__(BLOCK) void k_trace(SceneDev S, Queues Q, uint32_t seg) {
     __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
+    __shared__ uint32_t s_base;
+    __shared__ uint32_t s_cnt[CLS_COUNT];
     Stack st;
     st.lds = lds_stack + threadIdx.x;
     st.stride = BLOCK;
@@ -179,43 +179,78 @@ __global__ __launch_bounds__(BLOCK) void k_trace(SceneDev S, Queues Q, uint32_t 
     st.spill_stride = Q.spill_stride;
     st.sp = 0;
     SegCtr *ctr = Q.ctr + seg;
-    const uint32_t n_in = ctr->ray_count;
+    const uint32_t n_in = rays_in(Q, seg);
     float4 *const *rq = Q.ray[seg & 1u];
     TraceCounters cnt;
     uint32_t n_traced = 0;
-    WaveFetch fetch(&ctr->trace_cursor);
+    bool started = false;
+    // A short queue is spread over as many workgroups as possible: a thread then traces fewer rays per
+    // chunk (down to one), so the launch lasts about one ray's traversal instead of RAYS_PER_THREAD.
+    const uint32_t per_thread = min((uint32_t)RAYS_PER_THREAD, max(1u, (n_in + gridDim.x * BLOCK - 1u) / (gridDim.x * BLOCK)));
+    const uint32_t chunk = per_thread * BLOCK;
     while (true) {
-        uint32_t base = fetch.next();
+        if (threadIdx.x == 0)
+            s_base = started ? gridDim.x * chunk + atomicAdd(&ctr->trace_cursor, chunk) : blockIdx.x * chunk;
+        if (threadIdx.x < CLS_COUNT) s_cnt[threadIdx.x] = 0;
+        started = true;
+        __syncthreads();
+        const uint32_t base = s_base;
         if (base >= n_in) break;
-        uint32_t i = base + lane_id();
-        bool valid = i < n_in;
-        uint32_t ii = valid ? i : n_in - 1u;
-        float4 a = rq[0][ii], b = rq[1][ii], c = rq[2][ii];
-        PathState p = unpack_ray(a, b, c);
-        Best best;
-        best.t = V4R_INF;
-        best.prim = NO_PRIM;
-        best.u = best.v = 0.0f;
-        if (valid) {
-            traverse<COUNT>(S, p.o, p.d, st, best, cnt);
-            n_traced++;
-        }
-        bool hit = valid && best.prim != NO_PRIM;
-        if (valid && !hit)  // renderer.rs:184: a miss takes the background colour
-            Q.rad[p.slot] = make_float4(p.thr.x * S.bg[0], p.thr.y * S.bg[1], p.thr.z * S.bg[2], 0.0f);
-        uint32_t cls = hit ? (S.prim_info[best.prim] >> 24) : 0xFFu;
-        float4 dcol = make_float4(best.t, __uint_as_float(best.prim), best.u, best.v);
+        uint32_t where[RAYS_PER_THREAD];  // class << 16 | rank within the chunk's hits of that class
 #pragma unroll
-        for (uint32_t k = 0; k < CLS_COUNT; ++k) {
-            bool mine = hit && cls == k;
-            uint32_t idx = wave_push(mine, &ctr->hit_count[k]);
-            if (mine) {
-                Q.hit[k][0][idx] = a;
-                Q.hit[k][1][idx] = b;
-                Q.hit[k][2][idx] = c;
-                Q.hit[k][3][idx] = dcol;
+        for (int j = 0; j < RAYS_PER_THREAD; ++j) {
+            uint32_t i = base + (uint32_t)j * BLOCK + threadIdx.x;
+            bool valid = (uint32_t)j < per_thread && i < n_in;
+            uint32_t ii = valid ? i : n_in - 1u;
+            float4 a = rq[0][ii], b = rq[1][ii], c = rq[2][ii];
+            PathState p = unpack_ray(a, b, c);
+            Best best;
+            best.t = V4R_INF;
+            best.prim = NO_PRIM;
+            best.u = best.v = 0.0f;
+            if (valid) {
+                traverse<COUNT>(S, p.o, p.d, st, best, cnt);
+                n_traced++;
+            }
+            bool hit = valid && best.prim != NO_PRIM;
+            if (valid && !hit)  // renderer.rs:184: a miss takes the background colour
+                Q.rad[p.slot] = make_float4(p.thr.x * S.bg[0], p.thr.y * S.bg[1], p.thr.z * S.bg[2], 0.0f);
+            uint32_t cls = hit ? (S.prim_info[best.prim] >> 24) : 0xFFu;
+            if (hit) Q.hitd[i] = make_float4(best.t, __uint_as_float(best.prim), best.u, best.v);
+            uint32_t w = 0xFFFFFFFFu;
+#pragma unroll
+            for (uint32_t k = 0; k < CLS_COUNT; ++k) {
+                bool mine = hit && cls == k;
+                unsigned long long mask = __ballot(mine);
+                if (mask != 0ull) {
+                    uint32_t wbase = 0;
+                    if (lane_id() == 0) wbase = atomicAdd(&s_cnt[k], (uint32_t)__popcll(mask));
+                    wbase = __builtin_amdgcn_readfirstlane(wbase);
+                    uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                    if (mine) w = (k << 16) | (wbase + rank);
+                }
+            }
+            where[j] = w;
+        }
+        __syncthreads();
+        if (threadIdx.x < CLS_COUNT) {
+            uint32_t n = s_cnt[threadIdx.x];
+            s_cnt[threadIdx.x] = n ? atomicAdd(&ctr->hit_count[threadIdx.x], n) : 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < RAYS_PER_THREAD; ++j) {
+            uint32_t w = where[j];
+            if (w != 0xFFFFFFFFu) {
+                uint32_t i = base + (uint32_t)j * BLOCK + threadIdx.x;
+                uint32_t k = w >> 16, idx = s_cnt[k] + (w & 0xFFFFu);
+                Q.hit[k][0][idx] = rq[0][i];
+                Q.hit[k][1][idx] = rq[1][i];
+                Q.hit[k][2][idx] = rq[2][i];
+                Q.hit[k][3][idx] = Q.hitd[i];
             }
         }
+        __syncthreads();
     }
     if (COUNT) {
         unsigned long long s = wave_sum(n_traced), n = wave_sum(cnt.nodes), q = wave_sum(cnt.prims);
@@ -237,11 +272,11 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, Queues Q, uint32_t 
     float4 *const *hq = Q.hit[CLS];
     float4 *const *out = Q.ray[(seg + 1u) & 1u];
     const bool last = seg + 1u >= S.max_depth;
+    const uint32_t out_base = class_base(Q, seg, CLS);
     uint32_t n_shaded = 0, texel_fetches = 0;
-    WaveFetch fetch(&ctr->shade_cursor[CLS]);
-    while (true) {
-        uint32_t base = fetch.next();
-        if (base >= n_in) break;
+    // shading cost is uniform per hit: waves walk the class queue in fixed 64-entry strides
+    const uint32_t wave_stride = gridDim.x * (BLOCK / 64u) * 64u;
+    for (uint32_t base = (blockIdx.x * (BLOCK / 64u) + (threadIdx.x >> 6)) * 64u; base < n_in; base += wave_stride) {
         uint32_t i = base + lane_id();
         bool valid = i < n_in;
         uint32_t ii = valid ? i : n_in - 1u;
@@ -345,9 +380,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, Queues Q, uint32_t 
         q.k1 = p.k1;
         if (last) {  // renderer.rs:128-130: the depth budget is spent, the child returns `environment`
             if (valid) Q.rad[p.slot] = make_float4(q.thr.x * S.env[0], q.thr.y * S.env[1], q.thr.z * S.env[2], 0.0f);
-        } else {
-            uint32_t idx = wave_push(valid, &Q.ctr[seg + 1u].ray_count);
-            if (valid) store_ray(out, idx, q);
+        } else if (valid) {
+            store_ray(out, out_base + i, q);  // hit i of this class -> ray out_base + i of the next segment
         }
     }
     if (COUNT) {
@@ -433,11 +467,25 @@ int set_error(int code, const std::string &msg) {
 
 }  // namespace
 
+// One batch pipeline: a stream with its own queues.  Consecutive batches go to different pipelines so
+// that the long, nearly empty tail of one batch (a few paths bouncing up to max_depth times) overlaps
+// the wide first segments of the next.
+struct Pipe {
+    hipStream_t stream = nullptr;
+    Queues Q{};
+    hipEvent_t done = nullptr;  // recorded after the pipeline's latest k_resolve
+    bool used = false;
+};
+
 struct v4r_renderer {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;  // public stream = pipeline 0's
     SceneDev S{};
-    Queues Q{};
+    std::vector<Pipe> pipes;
+    uint32_t next_pipe = 0;
+    hipEvent_t last_resolve = nullptr;  // `done` of the pipeline that ran the latest batch
+    hipEvent_t fork = nullptr;
+    unsigned long long *stats = nullptr;
     std::vector<void *> allocations;
     float *accum_own = nullptr, *accum = nullptr;
     uint8_t *tonemap_buf = nullptr;
@@ -685,27 +733,38 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     }
     r->batch_passes = (uint32_t)std::max<size_t>(1, std::min<size_t>(target / r->npix, 4096));
     if ((uint64_t)r->batch_passes * r->npix > 0x7FFFFFFFull) r->batch_passes = (uint32_t)(0x7FFFFFFFull / r->npix);
-    Queues &Q = r->Q;
-    Q.cap = r->batch_passes * r->npix;
-    for (int p = 0; p < 2; ++p)
-        for (int c = 0; c < 3; ++c)
-            if (int rc = r->alloc(&Q.ray[p][c], Q.cap)) return rc;
-    for (int k = 0; k < CLS_COUNT; ++k)
-        for (int c = 0; c < 4; ++c)
-            if (int rc = r->alloc(&Q.hit[k][c], r->has_class[k] ? Q.cap : 1)) return rc;
-    if (int rc = r->alloc(&Q.rad, Q.cap)) return rc;
-    r->ctr_bytes = sizeof(SegCtr) * ((size_t)d->max_depth + 1);
-    if (int rc = r->alloc(&Q.ctr, (size_t)d->max_depth + 1)) return rc;
-    HIP_TRY(hipMemset(Q.ctr, 0, r->ctr_bytes));
-    if (int rc = r->alloc(&Q.stats, 8)) return rc;
-    HIP_TRY(hipMemset(Q.stats, 0, 64));
-
-    r->grid_trace = std::max(grid_for(k_trace<false>, n_cu), grid_for(k_trace_rays, n_cu));
+    uint32_t n_pipes = 3;
+    if (const char *env = std::getenv("V4R_PIPES")) n_pipes = (uint32_t)std::max(1, std::min(4, std::atoi(env)));
+    r->grid_trace = std::max(grid_for(k_trace<false, TRACE_RAYS_PER_THREAD>, n_cu), grid_for(k_trace_rays, n_cu));
     r->grid_shade = (uint32_t)n_cu * 8u;
     r->grid_stream = (uint32_t)n_cu * 8u;
     uint32_t spill_depth = bvh_depth > (uint32_t)LDS_DEPTH ? bvh_depth - LDS_DEPTH : 0;
-    Q.spill_stride = r->grid_trace * BLOCK;
-    if (int rc = r->alloc(&Q.spill, (size_t)Q.spill_stride * std::max(spill_depth, 1u))) return rc;
+    r->ctr_bytes = sizeof(SegCtr) * ((size_t)d->max_depth + 1);
+    if (int rc = r->alloc(&r->stats, 8)) return rc;
+    HIP_TRY(hipMemset(r->stats, 0, 64));
+    HIP_TRY(hipEventCreateWithFlags(&r->fork, hipEventDisableTiming));
+    r->pipes.resize(n_pipes);
+    for (uint32_t pi = 0; pi < n_pipes; ++pi) {
+        Pipe &pipe = r->pipes[pi];
+        if (pi == 0) pipe.stream = r->stream;
+        else HIP_TRY(hipStreamCreateWithFlags(&pipe.stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&pipe.done, hipEventDisableTiming));
+        Queues &Q = pipe.Q;
+        Q.cap = r->batch_passes * r->npix;
+        for (int p = 0; p < 2; ++p)
+            for (int c = 0; c < 3; ++c)
+                if (int rc = r->alloc(&Q.ray[p][c], Q.cap)) return rc;
+        for (int k = 0; k < CLS_COUNT; ++k)
+            for (int c = 0; c < 4; ++c)
+                if (int rc = r->alloc(&Q.hit[k][c], r->has_class[k] ? Q.cap : 1)) return rc;
+        if (int rc = r->alloc(&Q.hitd, Q.cap)) return rc;
+        if (int rc = r->alloc(&Q.rad, Q.cap)) return rc;
+        if (int rc = r->alloc(&Q.ctr, (size_t)d->max_depth + 1)) return rc;
+        HIP_TRY(hipMemset(Q.ctr, 0, r->ctr_bytes));
+        Q.stats = r->stats;
+        Q.spill_stride = r->grid_trace * BLOCK;
+        if (int rc = r->alloc(&Q.spill, (size_t)Q.spill_stride * std::max(spill_depth, 1u))) return rc;
+    }
 
     if (int rc = r->alloc(&r->accum_own, (size_t)r->npix * 3)) return rc;
     HIP_TRY(hipMemset(r->accum_own, 0, (size_t)r->npix * 3 * sizeof(float)));
@@ -716,19 +775,18 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
 }
 
 template <int CLS>
-void launch_shade(v4r_renderer *r, uint32_t seg) {
+void launch_shade(v4r_renderer *r, Pipe &pipe, uint32_t seg) {
     if (!r->has_class[CLS]) return;
-    Queues Q = r->Q;
-    if (r->counting) hipLaunchKernelGGL((k_shade<CLS, true>), dim3(r->grid_shade), dim3(BLOCK), 0, r->stream, r->S, Q, seg);
-    else hipLaunchKernelGGL((k_shade<CLS, false>), dim3(r->grid_shade), dim3(BLOCK), 0, r->stream, r->S, Q, seg);
+    if (r->counting) hipLaunchKernelGGL((k_shade<CLS, true>), dim3(r->grid_shade), dim3(BLOCK), 0, pipe.stream, r->S, pipe.Q, seg);
+    else hipLaunchKernelGGL((k_shade<CLS, false>), dim3(r->grid_shade), dim3(BLOCK), 0, pipe.stream, r->S, pipe.Q, seg);
 }
 
-int run_batch(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_t pass_stride, uint32_t n_batch_passes) {
-    Queues Q = r->Q;
+int run_batch(v4r_renderer *r, Pipe &pipe, uint64_t seed, uint32_t first_pass, uint32_t pass_stride, uint32_t n_batch_passes) {
+    Queues Q = pipe.Q;
     if (!r->counting) Q.stats = nullptr;
     uint32_t n_paths = n_batch_passes * r->npix;
-    HIP_TRY(hipMemsetAsync(r->Q.ctr, 0, r->ctr_bytes, r->stream));
-    hipLaunchKernelGGL(k_raygen, dim3(r->grid_stream), dim3(BLOCK), 0, r->stream, r->S, Q, (uint32_t)seed, (uint32_t)(seed >> 32),
+    HIP_TRY(hipMemsetAsync(pipe.Q.ctr, 0, r->ctr_bytes, pipe.stream));
+    hipLaunchKernelGGL(k_raygen, dim3(r->grid_stream), dim3(BLOCK), 0, pipe.stream, r->S, Q, (uint32_t)seed, (uint32_t)(seed >> 32),
                        first_pass, pass_stride, n_paths);
     for (uint32_t seg = 0; seg < r->S.max_depth; ++seg) {
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -742,20 +800,44 @@ int run_batch(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_t pass
             }
             ev0 = r->ev_pool[r->ev_used++];
             ev1 = r->ev_pool[r->ev_used++];
-            HIP_TRY(hipEventRecord(ev0, r->stream));
+            HIP_TRY(hipEventRecord(ev0, pipe.stream));
         }
-        if (r->counting) hipLaunchKernelGGL(k_trace<true>, dim3(r->grid_trace), dim3(BLOCK), 0, r->stream, r->S, r->Q, seg);
-        else hipLaunchKernelGGL(k_trace<false>, dim3(r->grid_trace), dim3(BLOCK), 0, r->stream, r->S, r->Q, seg);
-        if (r->profiling) HIP_TRY(hipEventRecord(ev1, r->stream));
-        launch_shade<CLS_LIGHT>(r, seg);
-        launch_shade<CLS_LAMBERT>(r, seg);
-        launch_shade<CLS_LAMBERT_NOISE>(r, seg);
-        launch_shade<CLS_METAL>(r, seg);
-        launch_shade<CLS_DIELECTRIC>(r, seg);
-        launch_shade<CLS_ISOTROPIC>(r, seg);
+        if (r->counting) hipLaunchKernelGGL((k_trace<true, TRACE_RAYS_PER_THREAD>), dim3(r->grid_trace), dim3(BLOCK), 0, pipe.stream, r->S, pipe.Q, seg);
+        else hipLaunchKernelGGL((k_trace<false, TRACE_RAYS_PER_THREAD>), dim3(r->grid_trace), dim3(BLOCK), 0, pipe.stream, r->S, pipe.Q, seg);
+        if (r->profiling) HIP_TRY(hipEventRecord(ev1, pipe.stream));
+        launch_shade<CLS_LIGHT>(r, pipe, seg);
+        launch_shade<CLS_LAMBERT>(r, pipe, seg);
+        launch_shade<CLS_LAMBERT_NOISE>(r, pipe, seg);
+        launch_shade<CLS_METAL>(r, pipe, seg);
+        launch_shade<CLS_DIELECTRIC>(r, pipe, seg);
+        launch_shade<CLS_ISOTROPIC>(r, pipe, seg);
     }
-    hipLaunchKernelGGL(k_resolve, dim3(r->grid_stream), dim3(BLOCK), 0, r->stream, r->Q, r->accum, r->npix, n_batch_passes);
+    // accumulate in batch order: this batch's k_resolve runs after the previous batch's
+    if (r->last_resolve && r->last_resolve != pipe.done) HIP_TRY(hipStreamWaitEvent(pipe.stream, r->last_resolve, 0));
+    hipLaunchKernelGGL(k_resolve, dim3(r->grid_stream), dim3(BLOCK), 0, pipe.stream, pipe.Q, r->accum, r->npix, n_batch_passes);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(pipe.done, pipe.stream));
+    r->last_resolve = pipe.done;
+    pipe.used = true;
+    return V4R_OK;
+}
+
+// Work queued on the public stream so far happens before anything the other pipelines do next.
+int fork_pipes(v4r_renderer *r) {
+    if (r->pipes.size() < 2) return V4R_OK;
+    HIP_TRY(hipEventRecord(r->fork, r->stream));
+    for (size_t i = 1; i < r->pipes.size(); ++i) HIP_TRY(hipStreamWaitEvent(r->pipes[i].stream, r->fork, 0));
+    return V4R_OK;
+}
+// Everything the pipelines have queued happens before whatever is queued on the public stream next.
+int join_pipes(v4r_renderer *r) {
+    // a pipeline's last queued operation is always its `done` record (after k_resolve)
+    for (size_t i = 1; i < r->pipes.size(); ++i)
+        if (r->pipes[i].used) HIP_TRY(hipStreamWaitEvent(r->stream, r->pipes[i].done, 0));
+    return V4R_OK;
+}
+int sync_all(v4r_renderer *r) {
+    for (auto &p : r->pipes) HIP_TRY(hipStreamSynchronize(p.stream));
     return V4R_OK;
 }
 
@@ -790,10 +872,15 @@ int v4r_renderer_create(const v4r_scene_desc *desc, int device, v4r_renderer **o
 void v4r_renderer_destroy(v4r_renderer *r) {
     if (!r) return;
     (void)hipSetDevice(r->device);
-    if (r->stream) {
-        (void)hipStreamSynchronize(r->stream);
-        (void)hipStreamDestroy(r->stream);
-    }
+    for (auto &p : r->pipes)
+        if (p.stream) (void)hipStreamSynchronize(p.stream);
+    if (r->stream) (void)hipStreamSynchronize(r->stream);
+    for (size_t i = 1; i < r->pipes.size(); ++i)
+        if (r->pipes[i].stream) (void)hipStreamDestroy(r->pipes[i].stream);
+    if (r->stream) (void)hipStreamDestroy(r->stream);
+    for (auto &p : r->pipes)
+        if (p.done) (void)hipEventDestroy(p.done);
+    if (r->fork) (void)hipEventDestroy(r->fork);
     for (void *p : r->allocations) (void)hipFree(p);
     for (hipEvent_t e : r->ev_pool) (void)hipEventDestroy(e);
     delete r;
@@ -803,12 +890,16 @@ int v4r_render(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_t pas
     if (!r) return set_error(V4R_E_INVALID, "NULL renderer");
     if (pass_stride == 0) pass_stride = 1;
     HIP_TRY(hipSetDevice(r->device));
+    if (int rc = fork_pipes(r)) return rc;
     uint32_t done = 0;
     while (done < n_passes) {
         uint32_t nb = std::min(r->batch_passes, n_passes - done);
-        if (int rc = run_batch(r, seed, first_pass + done * pass_stride, pass_stride, nb)) return rc;
+        Pipe &pipe = r->pipes[r->next_pipe];
+        r->next_pipe = (r->next_pipe + 1) % (uint32_t)r->pipes.size();
+        if (int rc = run_batch(r, pipe, seed, first_pass + done * pass_stride, pass_stride, nb)) return rc;
         done += nb;
     }
+    if (int rc = join_pipes(r)) return rc;
     r->n_passes += n_passes;
     return V4R_OK;
 }
@@ -878,7 +969,7 @@ static int trace_common(v4r_renderer *r, uint32_t n, const float *host_origin, c
     if (e == hipSuccess) e = hipMalloc((void **)&d_t, (size_t)n * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&d_p, (size_t)n * sizeof(uint32_t));
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_trace_rays, dim3(r->grid_trace), dim3(BLOCK), 0, r->stream, r->S, r->Q, n, d_o, d_d, d_p, d_t);
+        hipLaunchKernelGGL(k_trace_rays, dim3(r->grid_trace), dim3(BLOCK), 0, r->stream, r->S, r->pipes[0].Q, n, d_o, d_d, d_p, d_t);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
@@ -913,14 +1004,14 @@ int v4r_stats_read(v4r_renderer *r, v4r_stats *out, int reset) {
     HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(hipStreamSynchronize(r->stream));
     unsigned long long h[8];
-    HIP_TRY(hipMemcpy(h, r->Q.stats, sizeof h, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h, r->stats, sizeof h, hipMemcpyDeviceToHost));
     out->segments = h[0];
     out->nodes = h[1];
     out->prims = h[2];
     out->paths = h[3];
     out->shaded = h[4];
     out->texel_fetches = h[5];
-    if (reset) HIP_TRY(hipMemset(r->Q.stats, 0, 64));
+    if (reset) HIP_TRY(hipMemset(r->stats, 0, 64));
     return V4R_OK;
 }
 
