@@ -164,14 +164,19 @@ V4R_DEV uint32_t class_base(const Queues &Q, uint32_t seg, int cls) {
 
 // BVH traversal + closest hit for the rays of one segment.  A workgroup takes RAYS_PER_THREAD*256 rays
 // at a time (the chunk at its own grid position first, then chunks from a shared cursor: one global
-// atomic per chunk), traces them, ranks the hits of the chunk per shading class in LDS (wave64 ballot +
-// mbcnt prefix, one LDS atomic per wave and class), reserves the chunk's slots in each class queue with
-// one global atomic per class, and copies the ray + hit records there.
+// atomic per chunk); each lane traces RAYS_PER_THREAD rays of the chunk one after the other.  Within a
+// wave the traversal alternates, by vote, between stepping through interior nodes and intersecting the
+// leaves that lanes have parked.  A hit is ranked within its shading class in LDS; when the chunk is
+// done the workgroup reserves its slots in each class queue with one global atomic per class and
+// copies the ray + hit records there.  (Letting a lane start its next ray while its neighbours are
+// still inside the previous one was measured and lost 10-15 %: the extra votes and the divergent
+// fetch cost more than the idle lanes they remove.)
 template <bool COUNT, int RAYS_PER_THREAD>
 __global__ __launch_bounds__(BLOCK) void k_trace(SceneDev S, Queues Q, uint32_t seg) {
     __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
     __shared__ uint32_t s_base;
     __shared__ uint32_t s_cnt[CLS_COUNT];
+    __shared__ uint32_t s_where[RAYS_PER_THREAD * BLOCK];  // per ray of the chunk: class << 16 | rank among the chunk's hits of that class
     Stack st;
     st.lds = lds_stack + threadIdx.x;
     st.stride = BLOCK;
@@ -196,41 +201,32 @@ __global__ __launch_bounds__(BLOCK) void k_trace(SceneDev S, Queues Q, uint32_t 
         __syncthreads();
         const uint32_t base = s_base;
         if (base >= n_in) break;
-        uint32_t where[RAYS_PER_THREAD];  // class << 16 | rank within the chunk's hits of that class
-#pragma unroll
-        for (int j = 0; j < RAYS_PER_THREAD; ++j) {
-            uint32_t i = base + (uint32_t)j * BLOCK + threadIdx.x;
-            bool valid = (uint32_t)j < per_thread && i < n_in;
-            uint32_t ii = valid ? i : n_in - 1u;
-            float4 a = rq[0][ii], b = rq[1][ii], c = rq[2][ii];
-            PathState p = unpack_ray(a, b, c);
-            Best best;
-            best.t = V4R_INF;
-            best.prim = NO_PRIM;
-            best.u = best.v = 0.0f;
-            if (valid) {
-                traverse<COUNT>(S, p.o, p.d, st, best, cnt);
-                n_traced++;
-            }
-            bool hit = valid && best.prim != NO_PRIM;
-            if (valid && !hit)  // renderer.rs:184: a miss takes the background colour
-                Q.rad[p.slot] = make_float4(p.thr.x * S.bg[0], p.thr.y * S.bg[1], p.thr.z * S.bg[2], 0.0f);
-            uint32_t cls = hit ? (S.prim_info[best.prim] >> 24) : 0xFFu;
-            if (hit) Q.hitd[i] = make_float4(best.t, __uint_as_float(best.prim), best.u, best.v);
-            uint32_t w = 0xFFFFFFFFu;
-#pragma unroll
-            for (uint32_t k = 0; k < CLS_COUNT; ++k) {
-                bool mine = hit && cls == k;
-                unsigned long long mask = __ballot(mine);
-                if (mask != 0ull) {
-                    uint32_t wbase = 0;
-                    if (lane_id() == 0) wbase = atomicAdd(&s_cnt[k], (uint32_t)__popcll(mask));
-                    wbase = __builtin_amdgcn_readfirstlane(wbase);
-                    uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                    if (mine) w = (k << 16) | (wbase + rank);
+
+        {
+#pragma unroll 1
+            for (uint32_t j = 0; j < per_thread; ++j) {
+                uint32_t i = base + j * BLOCK + threadIdx.x;
+                bool active = i < n_in;
+                uint32_t ii = active ? i : n_in - 1u;
+                float4 a = rq[0][ii];
+                float2 b = *reinterpret_cast<const float2 *>(&rq[1][ii]);
+                V3 o = v3(a.x, a.y, a.z), d = v3(a.w, b.x, b.y);
+                Best best;
+                if (COUNT && active) n_traced++;
+                traverse<COUNT>(S, o, d, active, st, best, cnt);
+                uint32_t w = 0xFFFFFFFFu;
+                if (active) {
+                    if (best.prim != NO_PRIM) {
+                        uint32_t cls = S.prim_info[best.prim] >> 24;
+                        Q.hitd[i] = make_float4(best.t, __uint_as_float(best.prim), best.u, best.v);
+                        w = (cls << 16) | atomicAdd(&s_cnt[cls], 1u);
+                    } else {  // renderer.rs:184: a miss takes the background colour
+                        float4 bb = rq[1][i], c = rq[2][i];
+                        Q.rad[__float_as_uint(c.y)] = make_float4(bb.z * S.bg[0], bb.w * S.bg[1], c.x * S.bg[2], 0.0f);
+                    }
                 }
+                s_where[j * BLOCK + threadIdx.x] = w;
             }
-            where[j] = w;
         }
         __syncthreads();
         if (threadIdx.x < CLS_COUNT) {
@@ -238,11 +234,11 @@ __global__ __launch_bounds__(BLOCK) void k_trace(SceneDev S, Queues Q, uint32_t 
             s_cnt[threadIdx.x] = n ? atomicAdd(&ctr->hit_count[threadIdx.x], n) : 0u;
         }
         __syncthreads();
-#pragma unroll
-        for (int j = 0; j < RAYS_PER_THREAD; ++j) {
-            uint32_t w = where[j];
+#pragma unroll 1
+        for (uint32_t j = 0; j < per_thread; ++j) {
+            uint32_t i = base + j * BLOCK + threadIdx.x;
+            uint32_t w = i < n_in ? s_where[j * BLOCK + threadIdx.x] : 0xFFFFFFFFu;  // slots past the queue end were never traced
             if (w != 0xFFFFFFFFu) {
-                uint32_t i = base + (uint32_t)j * BLOCK + threadIdx.x;
                 uint32_t k = w >> 16, idx = s_cnt[k] + (w & 0xFFFFu);
                 Q.hit[k][0][idx] = rq[0][i];
                 Q.hit[k][1][idx] = rq[1][i];
@@ -435,18 +431,25 @@ __global__ __launch_bounds__(BLOCK) void k_trace_rays(SceneDev S, Queues Q, uint
     st.sp = 0;
     uint32_t stride = gridDim.x * BLOCK;
     TraceCounters cnt;
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
-        V3 o, d;
-        if (origin) {
-            o = v3(origin[3 * (size_t)i], origin[3 * (size_t)i + 1], origin[3 * (size_t)i + 2]);
-            d = v3(dir[3 * (size_t)i], dir[3 * (size_t)i + 1], dir[3 * (size_t)i + 2]);
-        } else {
-            camera_ray(S, i, 0u, true, o, d);
+    // the loop bound is wave-uniform: traverse() votes across the wave
+    for (uint32_t base = blockIdx.x * BLOCK + (threadIdx.x & ~63u); base < n; base += stride) {
+        uint32_t i = base + lane_id();
+        bool valid = i < n;
+        V3 o = v3(0, 0, 0), d = v3(1, 0, 0);
+        if (valid) {
+            if (origin) {
+                o = v3(origin[3 * (size_t)i], origin[3 * (size_t)i + 1], origin[3 * (size_t)i + 2]);
+                d = v3(dir[3 * (size_t)i], dir[3 * (size_t)i + 1], dir[3 * (size_t)i + 2]);
+            } else {
+                camera_ray(S, i, 0u, true, o, d);
+            }
         }
         Best best;
-        traverse<false>(S, o, d, st, best, cnt);
-        prim_out[i] = best.prim;
-        t_out[i] = best.t;
+        traverse<false>(S, o, d, valid, st, best, cnt);
+        if (valid) {
+            prim_out[i] = best.prim;
+            t_out[i] = best.t;
+        }
     }
 }
 
@@ -726,7 +729,7 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
 
     // queues
     r->npix = d->width * d->height;
-    size_t target = 4u << 20;  // paths per batch
+    size_t target = 16u << 20;  // paths per batch
     if (const char *env = std::getenv("V4R_BATCH_PATHS")) {
         long long v = std::atoll(env);
         if (v > 0) target = (size_t)v;
@@ -834,10 +837,6 @@ int join_pipes(v4r_renderer *r) {
     // a pipeline's last queued operation is always its `done` record (after k_resolve)
     for (size_t i = 1; i < r->pipes.size(); ++i)
         if (r->pipes[i].used) HIP_TRY(hipStreamWaitEvent(r->stream, r->pipes[i].done, 0));
-    return V4R_OK;
-}
-int sync_all(v4r_renderer *r) {
-    for (auto &p : r->pipes) HIP_TRY(hipStreamSynchronize(p.stream));
     return V4R_OK;
 }
 

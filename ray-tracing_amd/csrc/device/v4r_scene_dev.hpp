@@ -68,21 +68,15 @@ V4R_DEV Prim load_prim(const float4 *prims, uint32_t i) {
 // Same running-interval test with strict tmin < tmax; the per-axis divisions become multiplications
 // by a reciprocal computed once per ray.
 V4R_DEV bool slab(V3 lo, V3 hi, V3 o, V3 inv, float &entry) {
-    float t_min = EPSILON, t_max = V4R_INF;
-    float a0 = (lo.x - o.x) * inv.x, a1 = (hi.x - o.x) * inv.x;
-    t_min = fmaxf(fminf(a0, a1), t_min);
-    t_max = fminf(fmaxf(a0, a1), t_max);
-    bool ok = t_min < t_max;
-    float b0 = (lo.y - o.y) * inv.y, b1 = (hi.y - o.y) * inv.y;
-    t_min = fmaxf(fminf(b0, b1), t_min);
-    t_max = fminf(fmaxf(b0, b1), t_max);
-    ok = ok && (t_min < t_max);
-    float c0 = (lo.z - o.z) * inv.z, c1 = (hi.z - o.z) * inv.z;
-    t_min = fmaxf(fminf(c0, c1), t_min);
-    t_max = fminf(fmaxf(c0, c1), t_max);
-    ok = ok && (t_min < t_max);
-    entry = t_min;
-    return ok;
+    float ax0 = (lo.x - o.x) * inv.x, ax1 = (hi.x - o.x) * inv.x;
+    float ay0 = (lo.y - o.y) * inv.y, ay1 = (hi.y - o.y) * inv.y;
+    float az0 = (lo.z - o.z) * inv.z, az1 = (hi.z - o.z) * inv.z;
+    // The running interval only ever shrinks, so testing tmin < tmax once after the third axis accepts
+    // exactly the boxes the per-axis tests accept; nested min/max map to v_min3_f32 / v_max3_f32.
+    float t_near = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fmaxf(fminf(az0, az1), EPSILON));
+    float t_far = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fmaxf(az0, az1));
+    entry = t_near;
+    return t_near < t_far;
 }
 
 // ---- primitive intersection (distance only) -----------------------------------------------------
@@ -199,63 +193,131 @@ struct Stack {
 };
 
 // BVH::traverse (bvh/bvh.rs:182-239) + closest-hit selection (renderer.rs:149-183), restructured
-// for a GPU lane: near child first, far child stacked with its entry distance, subtrees skipped
-// once their entry distance exceeds the closest hit.  The closest hit is the same one the
-// reference's candidate-set traversal selects.
+// for a wave of 64 rays.  Per ray: near child first, far child stacked with its entry distance,
+// subtrees skipped once their entry distance exceeds the closest hit; leaf children are tested right
+// after the node that holds them.  The closest hit is the same one the reference's candidate-set
+// traversal selects.  Across the wave the kinds of work run in separate phases, so that the
+// primitive-intersection code is not executed (mostly masked off) on every node step: a lane that
+// reaches a leaf parks it and idles while the other lanes keep stepping through interior nodes
+// (trav_step); once enough lanes are parked the parked leaves are intersected together
+// (trav_leaves).  The order of node visits and primitive tests of each ray is unchanged by the phasing.
+#ifndef V4R_VOTE_NUM
+#define V4R_VOTE_NUM 1
+#define V4R_VOTE_DEN 2
+#endif
+constexpr uint32_t TRAV_NONE = 0xFFFFFFFFu;
+
+struct Trav {
+    uint32_t node;         // interior node to visit next, TRAV_NONE when the ray is finished (or absent)
+    float node_entry;      // its box entry distance
+    uint32_t pend0, pend1; // parked leaf primitives of the last visited node (child 0's, child 1's)
+    float pend1_entry;
+    __device__ __forceinline__ bool parked() const { return (pend0 & pend1) != TRAV_NONE; }
+    __device__ __forceinline__ bool stepping() const { return node != TRAV_NONE && !parked(); }
+    __device__ __forceinline__ void start() {
+        node = 0u;
+        node_entry = 0.0f;  // the root has no box
+        pend0 = pend1 = TRAV_NONE;
+        pend1_entry = 0.0f;
+    }
+    __device__ __forceinline__ void clear() {
+        node = pend0 = pend1 = TRAV_NONE;
+        node_entry = pend1_entry = 0.0f;
+    }
+};
+
+V4R_DEV uint32_t pop_cull(Stack &st, float best_t) {
+    while (st.sp > 0) {
+        uint2 e = st.pop();
+        if (__uint_as_float(e.y) <= best_t) return e.x;
+    }
+    return TRAV_NONE;
+}
+
+// One interior-node visit of a lane with T.stepping(): both child boxes, leaf children parked,
+// interior children ordered near-first.
 template <bool COUNT>
-V4R_DEV void traverse(const SceneDev &S, V3 o, V3 d, Stack &st, Best &best, TraceCounters &cnt) {
+V4R_DEV void trav_step(const SceneDev &S, V3 o, V3 inv, Stack &st, const Best &best, Trav &T, TraceCounters &cnt) {
+    const float4 *np = S.nodes + 4 * (size_t)T.node;
+    float4 n0 = np[0], n1 = np[1], n2 = np[2];
+    float2 kids = *reinterpret_cast<const float2 *>(np + 3);
+    if (COUNT) cnt.nodes++;
+    float e0, e1;
+    bool h0 = slab(v3(n0.x, n0.y, n0.z), v3(n0.w, n1.x, n1.y), o, inv, e0) && e0 <= best.t;
+    bool h1 = slab(v3(n1.z, n1.w, n2.x), v3(n2.y, n2.z, n2.w), o, inv, e1) && e1 <= best.t;
+    uint32_t c0 = __float_as_uint(kids.x), c1 = __float_as_uint(kids.y);
+    bool l0 = h0 && (c0 & V4R_LEAF_BIT), l1 = h1 && (c1 & V4R_LEAF_BIT);
+    bool i0 = h0 && !l0, i1 = h1 && !l1;
+    T.pend0 = l0 ? (c0 & ~V4R_LEAF_BIT) : TRAV_NONE;
+    T.pend1 = l1 ? (c1 & ~V4R_LEAF_BIT) : TRAV_NONE;
+    T.pend1_entry = e1;
+    if (i0 && i1) {
+        bool first0 = e0 <= e1;
+        st.push(first0 ? c1 : c0, first0 ? e1 : e0);
+        T.node = first0 ? c0 : c1;
+        T.node_entry = first0 ? e0 : e1;
+    } else if (i0 || i1) {
+        T.node = i0 ? c0 : c1;
+        T.node_entry = i0 ? e0 : e1;
+    } else {
+        T.node = TRAV_NONE;
+    }
+    if (!(l0 || l1) && T.node == TRAV_NONE) T.node = pop_cull(st, best.t);
+}
+
+// Intersect the parked leaves of every lane of the wave (child 0's before child 1's), then settle
+// which node each of those lanes visits next.  Called by the whole wave.
+template <bool COUNT>
+V4R_DEV void trav_leaves(const SceneDev &S, V3 o, V3 d, Stack &st, Best &best, Trav &T, TraceCounters &cnt) {
+    bool parked = T.parked();
+#pragma unroll 1
+    for (int k = 0; k < 2; ++k) {
+        uint32_t prim = k == 0 ? T.pend0 : T.pend1;
+        // the first test may have shortened the interval past the second leaf's box
+        bool go = prim != TRAV_NONE && (k == 0 || T.pend1_entry <= best.t);
+        if (__ballot(go) == 0ull) continue;
+        if (go) {
+            if (COUNT) cnt.prims++;
+            consider(S, prim, o, d, best);
+        }
+    }
+    if (parked) {
+        if (T.node != TRAV_NONE && !(T.node_entry <= best.t)) T.node = TRAV_NONE;
+        if (T.node == TRAV_NONE) T.node = pop_cull(st, best.t);
+        T.pend0 = T.pend1 = TRAV_NONE;
+    }
+}
+
+// Closest hit of one ray per lane.  Must be called by every lane of the wave; lanes with
+// active == false only take part in the votes.
+template <bool COUNT>
+V4R_DEV void traverse(const SceneDev &S, V3 o, V3 d, bool active, Stack &st, Best &best, TraceCounters &cnt) {
     best.t = V4R_INF;
     best.prim = NO_PRIM;
     best.u = best.v = 0.0f;
     if (S.n_prims == 0) return;
     if (S.n_nodes == 0) {  // single shape: tested without any box (bvh.rs:218-224)
-        if (COUNT) cnt.prims++;
-        consider(S, 0, o, d, best);
+        if (active) {
+            if (COUNT) cnt.prims++;
+            consider(S, 0, o, d, best);
+        }
         return;
     }
     V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    uint32_t node = 0;
+    Trav T;
+    T.clear();
+    if (active) T.start();
     st.sp = 0;
     while (true) {
-        const float4 *np = S.nodes + 4 * (size_t)node;
-        float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-        if (COUNT) cnt.nodes++;
-        float e0, e1;
-        bool h0 = slab(v3(n0.x, n0.y, n0.z), v3(n0.w, n1.x, n1.y), o, inv, e0) && e0 <= best.t;
-        bool h1 = slab(v3(n1.z, n1.w, n2.x), v3(n2.y, n2.z, n2.w), o, inv, e1) && e1 <= best.t;
-        uint32_t c0 = __float_as_uint(n3.x), c1 = __float_as_uint(n3.y);
-        if (h0 && (c0 & V4R_LEAF_BIT)) {
-            if (COUNT) cnt.prims++;
-            consider(S, c0 & ~V4R_LEAF_BIT, o, d, best);
-            h0 = false;
+        while (true) {
+            unsigned long long m_step = __ballot(T.stepping());
+            if (m_step == 0ull) break;
+            unsigned long long m_parked = __ballot(T.parked());
+            if (m_parked != 0ull && __popcll(m_parked) * V4R_VOTE_DEN >= (__popcll(m_parked) + __popcll(m_step)) * V4R_VOTE_NUM) break;
+            if (T.stepping()) trav_step<COUNT>(S, o, inv, st, best, T, cnt);
         }
-        if (h1 && (c1 & V4R_LEAF_BIT)) {
-            if (e1 <= best.t) {
-                if (COUNT) cnt.prims++;
-                consider(S, c1 & ~V4R_LEAF_BIT, o, d, best);
-            }
-            h1 = false;
-        }
-        if (h0 && h1) {
-            bool first0 = e0 <= e1;
-            st.push(first0 ? c1 : c0, first0 ? e1 : e0);
-            node = first0 ? c0 : c1;
-            continue;
-        }
-        if (h0 || h1) {
-            node = h0 ? c0 : c1;
-            if ((h0 ? e0 : e1) <= best.t) continue;
-        }
-        bool found = false;
-        while (st.sp > 0) {
-            uint2 e = st.pop();
-            if (__uint_as_float(e.y) <= best.t) {
-                node = e.x;
-                found = true;
-                break;
-            }
-        }
-        if (!found) return;
+        if (__ballot(T.parked()) != 0ull) trav_leaves<COUNT>(S, o, d, st, best, T, cnt);
+        if (__ballot(T.node != TRAV_NONE) == 0ull) break;
     }
 }
 
