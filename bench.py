@@ -162,7 +162,11 @@ def main():
                     "algorithmic_bytes_per_path": round(bytes_per_step / (npix * spp), 2),
                     "nodes_per_segment": round(stats["nodes"] / stats["segments"], 3),
                     "prims_per_segment": round(stats["prims"] / stats["segments"], 3),
-                    "segments_per_path": round(stats["segments"] / stats["paths"], 3)}
+                    "segments_per_path": round(stats["segments"] / stats["paths"], 3),
+                    "lane_utilisation_node_step": round(stats["nodes"] / max(1, 64 * stats["wave_node_steps"]), 3),
+                    "lane_utilisation_prim_test": round(stats["prims"] / max(1, 64 * stats["wave_leaf_steps"]), 3),
+                    "wave_node_steps_per_wave_ray": round(64 * stats["wave_node_steps"] / stats["segments"], 2),
+                    "wave_prim_tests_per_wave_ray": round(64 * stats["wave_leaf_steps"] / stats["segments"], 2)}
     if world > 1:
         dist.barrier()
 

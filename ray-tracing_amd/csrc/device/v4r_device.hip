@@ -52,7 +52,7 @@ struct Queues {
     float4 *rad;                // per path slot: radiance of the finished path
     SegCtr *ctr;                // [max_depth + 1]
     uint2 *spill;               // traversal stack overflow, [entry][global thread]
-    unsigned long long *stats;  // segments, nodes, prims, paths, shaded, texel fetches
+    unsigned long long *stats;  // segments, nodes, prims, paths, shaded, texel fetches, wave node steps, wave leaf steps
     uint32_t spill_stride;
     uint32_t cap;               // path slots per batch
 };
@@ -121,17 +121,68 @@ V4R_DEV void camera_ray(const SceneDev &S, uint32_t pixel, uint32_t key, bool de
 }
 
 // ---- kernels ------------------------------------------------------------------------------------
+// Order of the camera rays in queue 0.  Neighbouring queue entries should be rays that do similar
+// work, at the first segment and, because the queues keep rays roughly in order, at the later ones
+// too: 64 consecutive entries (one wave of k_trace) hold a small tile of pixels times `1 << lp` passes
+// of the batch, e.g. 2x2 pixels x 16 passes.  Pixels outside whole tiles (odd image sizes) and passes
+// outside whole groups follow in plain order.  The map is a bijection, and since every random
+// number is keyed by (pass, pixel) the image does not depend on it.
+struct RayOrder {
+    uint32_t lp;            // log2 passes per tile
+    uint32_t tw_log, th_log;
+    uint32_t tiles_x;       // whole tiles per image row
+    uint32_t tiled_w, tiled_h;  // extent covered by whole tiles
+    uint32_t npix_tiled;    // tiled_w * tiled_h
+    uint32_t full_groups;   // groups of (1 << lp) passes in this batch
+};
+V4R_DEV void ray_order(const RayOrder &R, uint32_t width, uint32_t npix, uint32_t i, uint32_t &pass, uint32_t &pixel) {
+    const uint32_t group = npix << R.lp;
+    uint32_t g = i / group;
+    if (g >= R.full_groups) {
+        uint32_t q = i - R.full_groups * group;
+        uint32_t b = q / npix;
+        pass = (R.full_groups << R.lp) + b;
+        pixel = q - b * npix;
+        return;
+    }
+    uint32_t r = i - g * group, x, y;
+    if (r < (R.npix_tiled << R.lp)) {
+        uint32_t tile = r >> 6, w = r & 63u, pix_log = 6u - R.lp;
+        uint32_t pw = w & ((1u << pix_log) - 1u);
+        pass = (g << R.lp) + (w >> pix_log);
+        uint32_t ty = tile / R.tiles_x, tx = tile - ty * R.tiles_x;
+        x = (tx << R.tw_log) + (pw & ((1u << R.tw_log) - 1u));
+        y = (ty << R.th_log) + (pw >> R.tw_log);
+    } else {
+        uint32_t q = r - (R.npix_tiled << R.lp), n_rest = npix - R.npix_tiled;
+        uint32_t b = q / n_rest, qq = q - b * n_rest;
+        pass = (g << R.lp) + b;
+        uint32_t strip = width - R.tiled_w, n_right = strip * R.tiled_h;
+        if (qq < n_right) {  // columns right of the tiles
+            y = qq / strip;
+            x = R.tiled_w + (qq - y * strip);
+        } else {  // rows below the tiles
+            qq -= n_right;
+            uint32_t yy = qq / width;
+            y = R.tiled_h + yy;
+            x = qq - yy * width;
+        }
+    }
+    pixel = y * width + x;
+}
+
 __global__ __launch_bounds__(BLOCK) void k_raygen(SceneDev S, Queues Q, uint32_t seed_lo, uint32_t seed_hi,
-                                                  uint32_t first_pass, uint32_t pass_stride, uint32_t n_paths) {
+                                                  uint32_t first_pass, uint32_t pass_stride, uint32_t n_paths, RayOrder order) {
     uint32_t npix = S.width * S.height;
     uint32_t stride = gridDim.x * BLOCK;
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n_paths; i += stride) {
-        uint32_t b = i / npix, pixel = i - b * npix;
+        uint32_t b, pixel;
+        ray_order(order, S.width, npix, i, b, pixel);
         PathState p;
         path_key(seed_lo, seed_hi, first_pass + b * pass_stride, pixel, p.k0, p.k1);
         camera_ray(S, pixel, segment_key(p.k0, p.k1, 0), false, p.o, p.d);
         p.thr = v3(1, 1, 1);
-        p.slot = i;
+        p.slot = b * npix + pixel;
         store_ray(Q.ray[0], i, p);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -171,6 +222,169 @@ V4R_DEV uint32_t class_base(const Queues &Q, uint32_t seg, int cls) {
 // copies the ray + hit records there.  (Letting a lane start its next ray while its neighbours are
 // still inside the previous one was measured and lost 10-15 %: the extra votes and the divergent
 // fetch cost more than the idle lanes they remove.)
+// Variant of k_trace in which a lane takes its next ray as soon as its current one is finished.  Rays
+// of the chunk are handed out through a ticket counter in LDS; every lane keeps the ray after its
+// current one already loaded in registers, so starting it costs no memory latency.  A finished ray
+// only stores (t, prim, u, v); class ranking, misses and the copy into the class queues are done for
+// the whole chunk at its end, by all lanes.
+template <bool COUNT, int RAYS_PER_THREAD>
+__global__ __launch_bounds__(BLOCK) void k_trace_dyn(SceneDev S, Queues Q, uint32_t seg) {
+    __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
+    __shared__ uint32_t s_base, s_next;
+    __shared__ uint32_t s_cnt[CLS_COUNT];
+    __shared__ uint16_t s_where[RAYS_PER_THREAD * BLOCK];  // per ray of the chunk: class << 12 | rank among the chunk's hits of that class
+    static_assert(RAYS_PER_THREAD * BLOCK <= 4096, "rank field of s_where is 12 bits");
+    Stack st;
+    st.lds = lds_stack + threadIdx.x;
+    st.stride = BLOCK;
+    st.spill = Q.spill + (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    st.spill_stride = Q.spill_stride;
+    st.sp = 0;
+    SegCtr *ctr = Q.ctr + seg;
+    const uint32_t n_in = rays_in(Q, seg);
+    float4 *const *rq = Q.ray[seg & 1u];
+    TraceCounters cnt;
+    uint32_t n_traced = 0;
+    bool started = false;
+    const uint32_t per_thread = min((uint32_t)RAYS_PER_THREAD, max(1u, (n_in + gridDim.x * BLOCK - 1u) / (gridDim.x * BLOCK)));
+    const uint32_t chunk = per_thread * BLOCK;
+    const bool single = S.n_nodes == 0;  // one primitive, no BVH (bvh.rs:218-224)
+    const uint32_t lane = lane_id();
+    while (true) {
+        if (threadIdx.x == 0) {
+            s_base = started ? gridDim.x * chunk + atomicAdd(&ctr->trace_cursor, chunk) : blockIdx.x * chunk;
+            s_next = 0;
+        }
+        if (threadIdx.x < CLS_COUNT) s_cnt[threadIdx.x] = 0;
+        started = true;
+        __syncthreads();
+        const uint32_t base = s_base;
+        if (base >= n_in) break;
+        const uint32_t n_here = min(chunk, n_in - base);
+
+        bool have = false, next_valid = false;
+        uint32_t cur_k = 0, next_k = 0;
+        V3 o = v3(0, 0, 0), d = v3(1, 0, 0), inv = v3(1, 1, 1), next_o = o, next_d = d;
+        Best best;
+        best.t = V4R_INF;
+        best.prim = NO_PRIM;
+        best.u = best.v = 0.0f;
+        Trav T;
+        T.clear();
+        bool want = true;  // this lane wants a ticket
+        while (true) {
+            // ---- lanes without a ray start the one they hold ready ...
+            if (!have && next_valid) {
+                o = next_o;
+                d = next_d;
+                cur_k = next_k;
+                inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                best.t = V4R_INF;
+                best.prim = NO_PRIM;
+                best.u = best.v = 0.0f;
+                st.sp = 0;
+                have = true;
+                next_valid = false;
+                want = true;
+                if (COUNT) n_traced++;
+                if (single) {
+                    T.clear();
+                    if (S.n_prims) {
+                        if (COUNT) cnt.prims++;
+                        consider(S, 0, o, d, best);
+                    }
+                } else {
+                    T.start();
+                }
+            }
+            // ---- ... and load the one after it (one LDS atomic per wave)
+            unsigned long long m_want = __ballot(want);
+            if (m_want != 0ull) {
+                uint32_t t0 = 0;
+                if (lane == (uint32_t)__ffsll((long long)m_want) - 1u) t0 = atomicAdd(&s_next, (uint32_t)__popcll(m_want));
+                t0 = __shfl(t0, __ffsll((long long)m_want) - 1);
+                if (want) {
+                    uint32_t k = t0 + (uint32_t)__popcll(m_want & ((1ull << lane) - 1ull));
+                    want = false;
+                    if (k < n_here) {
+                        float4 a = rq[0][base + k];
+                        float2 b = *reinterpret_cast<const float2 *>(&rq[1][base + k]);
+                        next_o = v3(a.x, a.y, a.z);
+                        next_d = v3(a.w, b.x, b.y);
+                        next_k = k;
+                        next_valid = true;
+                    }
+                }
+                if (__ballot(!have && next_valid) != 0ull) continue;  // first round of the chunk: nothing to trace yet
+            }
+            if (__ballot(have) == 0ull) break;  // the chunk has no rays left for this wave
+            // ---- interior nodes, until enough lanes wait for another phase
+            while (true) {
+                bool stepping = have && T.stepping();
+                unsigned long long m_step = __ballot(stepping);
+                if (m_step == 0ull) break;
+                bool finished = have && T.node == TRAV_NONE && !T.parked();
+                bool waiting = (have && T.parked()) || (finished && next_valid);
+                unsigned long long m_wait = __ballot(waiting);
+                if (m_wait != 0ull && __popcll(m_wait) * V4R_VOTE_DEN >= (__popcll(m_wait) + __popcll(m_step)) * V4R_VOTE_NUM) break;
+                if (COUNT) cnt.wave_steps++;
+                if (stepping) trav_step<COUNT>(S, o, inv, st, best, T, cnt);
+            }
+            // ---- parked leaves
+            if (__ballot(have && T.parked()) != 0ull) trav_leaves<COUNT>(S, o, d, st, best, T, cnt);
+            // ---- finished rays leave their result
+            if (have && T.node == TRAV_NONE && !T.parked()) {
+                Q.hitd[base + cur_k] = make_float4(best.t, __uint_as_float(best.prim), best.u, best.v);
+                have = false;
+            }
+        }
+        __syncthreads();  // also makes the hitd records of the chunk visible to the whole workgroup
+#pragma unroll 1
+        for (uint32_t k = threadIdx.x; k < n_here; k += BLOCK) {
+            uint32_t i = base + k;
+            uint32_t prim = __float_as_uint(Q.hitd[i].y);
+            uint32_t w = 0xFFFFu;
+            if (prim != NO_PRIM) {
+                uint32_t cls = S.prim_info[prim] >> 24;
+                w = (cls << 12) | atomicAdd(&s_cnt[cls], 1u);
+            } else {  // renderer.rs:184: a miss takes the background colour
+                float4 bb = rq[1][i], c = rq[2][i];
+                Q.rad[__float_as_uint(c.y)] = make_float4(bb.z * S.bg[0], bb.w * S.bg[1], c.x * S.bg[2], 0.0f);
+            }
+            s_where[k] = (uint16_t)w;
+        }
+        __syncthreads();
+        if (threadIdx.x < CLS_COUNT) {
+            uint32_t n = s_cnt[threadIdx.x];
+            s_cnt[threadIdx.x] = n ? atomicAdd(&ctr->hit_count[threadIdx.x], n) : 0u;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (uint32_t k = threadIdx.x; k < n_here; k += BLOCK) {
+            uint32_t i = base + k;
+            uint32_t w = s_where[k];
+            if (w != 0xFFFFu) {
+                uint32_t c = w >> 12, idx = s_cnt[c] + (w & 0xFFFu);
+                Q.hit[c][0][idx] = rq[0][i];
+                Q.hit[c][1][idx] = rq[1][i];
+                Q.hit[c][2][idx] = rq[2][i];
+                Q.hit[c][3][idx] = Q.hitd[i];
+            }
+        }
+        __syncthreads();
+    }
+    if (COUNT) {
+        unsigned long long s = wave_sum(n_traced), n = wave_sum(cnt.nodes), q = wave_sum(cnt.prims);
+        if (lane_id() == 0) {
+            atomicAdd(&Q.stats[0], s);
+            atomicAdd(&Q.stats[1], n);
+            atomicAdd(&Q.stats[2], q);
+            atomicAdd(&Q.stats[6], (unsigned long long)cnt.wave_steps);
+            atomicAdd(&Q.stats[7], (unsigned long long)cnt.wave_leaves);
+        }
+    }
+}
+
 template <bool COUNT, int RAYS_PER_THREAD>
 __global__ __launch_bounds__(BLOCK) void k_trace(SceneDev S, Queues Q, uint32_t seg) {
     __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
@@ -254,6 +468,8 @@ __global__ __launch_bounds__(BLOCK) void k_trace(SceneDev S, Queues Q, uint32_t 
             atomicAdd(&Q.stats[0], s);
             atomicAdd(&Q.stats[1], n);
             atomicAdd(&Q.stats[2], q);
+            atomicAdd(&Q.stats[6], (unsigned long long)cnt.wave_steps);
+            atomicAdd(&Q.stats[7], (unsigned long long)cnt.wave_leaves);
         }
     }
 }
@@ -729,13 +945,14 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
 
     // queues
     r->npix = d->width * d->height;
-    size_t target = 16u << 20;  // paths per batch
+    size_t target = 32u << 20;  // paths per batch
     if (const char *env = std::getenv("V4R_BATCH_PATHS")) {
         long long v = std::atoll(env);
         if (v > 0) target = (size_t)v;
     }
     r->batch_passes = (uint32_t)std::max<size_t>(1, std::min<size_t>(target / r->npix, 4096));
     if ((uint64_t)r->batch_passes * r->npix > 0x7FFFFFFFull) r->batch_passes = (uint32_t)(0x7FFFFFFFull / r->npix);
+    if (r->batch_passes >= 16u) r->batch_passes &= ~15u;  // whole groups of passes for the tiled ray order of k_raygen
     uint32_t n_pipes = 3;
     if (const char *env = std::getenv("V4R_PIPES")) n_pipes = (uint32_t)std::max(1, std::min(4, std::atoi(env)));
     r->grid_trace = std::max(grid_for(k_trace<false, TRACE_RAYS_PER_THREAD>, n_cu), grid_for(k_trace_rays, n_cu));
@@ -789,8 +1006,22 @@ int run_batch(v4r_renderer *r, Pipe &pipe, uint64_t seed, uint32_t first_pass, u
     if (!r->counting) Q.stats = nullptr;
     uint32_t n_paths = n_batch_passes * r->npix;
     HIP_TRY(hipMemsetAsync(pipe.Q.ctr, 0, r->ctr_bytes, pipe.stream));
+    RayOrder order;
+    {
+        static const int lp_max = getenv("V4R_TILE_PASSES_LOG2") ? std::min(6, std::max(0, atoi(getenv("V4R_TILE_PASSES_LOG2")))) : 4;
+        uint32_t lp = 0;
+        while ((int)lp < lp_max && (2u << lp) <= n_batch_passes) ++lp;
+        order.lp = lp;
+        order.tw_log = (6u - lp + 1u) / 2u;
+        order.th_log = (6u - lp) / 2u;
+        order.tiles_x = r->S.width >> order.tw_log;
+        order.tiled_w = order.tiles_x << order.tw_log;
+        order.tiled_h = (r->S.height >> order.th_log) << order.th_log;
+        order.npix_tiled = order.tiled_w * order.tiled_h;
+        order.full_groups = n_batch_passes >> lp;
+    }
     hipLaunchKernelGGL(k_raygen, dim3(r->grid_stream), dim3(BLOCK), 0, pipe.stream, r->S, Q, (uint32_t)seed, (uint32_t)(seed >> 32),
-                       first_pass, pass_stride, n_paths);
+                       first_pass, pass_stride, n_paths, order);
     for (uint32_t seg = 0; seg < r->S.max_depth; ++seg) {
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         if (r->profiling) {
@@ -805,7 +1036,11 @@ int run_batch(v4r_renderer *r, Pipe &pipe, uint64_t seed, uint32_t first_pass, u
             ev1 = r->ev_pool[r->ev_used++];
             HIP_TRY(hipEventRecord(ev0, pipe.stream));
         }
-        if (r->counting) hipLaunchKernelGGL((k_trace<true, TRACE_RAYS_PER_THREAD>), dim3(r->grid_trace), dim3(BLOCK), 0, pipe.stream, r->S, pipe.Q, seg);
+        static const int dyn = getenv("V4R_TRACE_DYN") ? atoi(getenv("V4R_TRACE_DYN")) : 0;
+        if (dyn) {
+            if (r->counting) hipLaunchKernelGGL((k_trace_dyn<true, 8>), dim3(r->grid_trace), dim3(BLOCK), 0, pipe.stream, r->S, pipe.Q, seg);
+            else hipLaunchKernelGGL((k_trace_dyn<false, 8>), dim3(r->grid_trace), dim3(BLOCK), 0, pipe.stream, r->S, pipe.Q, seg);
+        } else if (r->counting) hipLaunchKernelGGL((k_trace<true, TRACE_RAYS_PER_THREAD>), dim3(r->grid_trace), dim3(BLOCK), 0, pipe.stream, r->S, pipe.Q, seg);
         else hipLaunchKernelGGL((k_trace<false, TRACE_RAYS_PER_THREAD>), dim3(r->grid_trace), dim3(BLOCK), 0, pipe.stream, r->S, pipe.Q, seg);
         if (r->profiling) HIP_TRY(hipEventRecord(ev1, pipe.stream));
         launch_shade<CLS_LIGHT>(r, pipe, seg);
@@ -1010,6 +1245,8 @@ int v4r_stats_read(v4r_renderer *r, v4r_stats *out, int reset) {
     out->paths = h[3];
     out->shaded = h[4];
     out->texel_fetches = h[5];
+    out->wave_node_steps = h[6];
+    out->wave_leaf_steps = h[7];
     if (reset) HIP_TRY(hipMemset(r->stats, 0, 64));
     return V4R_OK;
 }

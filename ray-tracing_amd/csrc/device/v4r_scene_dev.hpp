@@ -138,6 +138,7 @@ V4R_DEV void to_object(const float *x, V3 &o, V3 &d, float &nrm) {
 
 struct TraceCounters {
     uint32_t nodes = 0, prims = 0;
+    uint32_t wave_steps = 0, wave_leaves = 0;  // counted by every lane of the wave, whether it takes part or not
 };
 
 // Closest hit so far during traversal.
@@ -276,6 +277,7 @@ V4R_DEV void trav_leaves(const SceneDev &S, V3 o, V3 d, Stack &st, Best &best, T
         // the first test may have shortened the interval past the second leaf's box
         bool go = prim != TRAV_NONE && (k == 0 || T.pend1_entry <= best.t);
         if (__ballot(go) == 0ull) continue;
+        if (COUNT) cnt.wave_leaves++;
         if (go) {
             if (COUNT) cnt.prims++;
             consider(S, prim, o, d, best);
@@ -314,6 +316,7 @@ V4R_DEV void traverse(const SceneDev &S, V3 o, V3 d, bool active, Stack &st, Bes
             if (m_step == 0ull) break;
             unsigned long long m_parked = __ballot(T.parked());
             if (m_parked != 0ull && __popcll(m_parked) * V4R_VOTE_DEN >= (__popcll(m_parked) + __popcll(m_step)) * V4R_VOTE_NUM) break;
+            if (COUNT) cnt.wave_steps++;
             if (T.stepping()) trav_step<COUNT>(S, o, inv, st, best, T, cnt);
         }
         if (__ballot(T.parked()) != 0ull) trav_leaves<COUNT>(S, o, d, st, best, T, cnt);

@@ -151,6 +151,26 @@ def test_batches_and_single_passes_are_bit_identical():
     r.close()
 
 
+@pytest.mark.parametrize("size,spp", [((37, 23), 21), ((8, 8), 70), ((5, 3), 3), ((64, 33), 16)])
+def test_ray_order_covers_every_pixel_and_pass(size, spp):
+    """The camera rays of a batch are queued tile by tile (pixels x passes), with leftover pixels and
+    passes in plain order: whatever the image size and pass count, each (pixel, pass) is rendered once,
+    so one batch equals the same passes rendered one at a time, bit for bit."""
+    scene = scenes.load("c3", *size)
+    r = Renderer(scene.renderer_param, scene.camera_param, scene)
+    r.render_passes(spp)
+    a, n = r.read_accumulator()
+    assert n == spp
+    r.clear()
+    for p in range(spp):
+        r.render_passes(1, first_pass=p)
+    b, _ = r.read_accumulator()
+    assert np.array_equal(a, b)
+    img_o, _ = oracle.render(r.desc, spp, seed=r.seed)
+    assert abs(a.mean() - img_o.mean()) <= 0.02 * abs(img_o.mean()) + 1e-6
+    r.close()
+
+
 def test_sample_split_over_ranks_matches_single_rank():
     """Rank r of N renders passes r, r+N, ...: the per-rank sums add up to the single-rank image
     (to fp32 reassociation) because pass p draws the same random streams wherever it runs."""
