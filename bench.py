@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5"])
     ap.add_argument("--spp", type=int, default=0, help="passes per GPU per step (default: the workload's full count)")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
@@ -178,6 +178,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: " + {
+                "c1": "data/scene.json verbatim (Cornell walls, 4 968-triangle bunny, fog sphere, 4 985 shapes)",
                 "c2": "Book-1 random-spheres scene (484 spheres, Lambertian/metal/dielectric)",
                 "c3": "Cornell box, cosine + light-list mixture sampling",
                 "c4": "bunny.obj subdivided to 79 488 triangles + earth-textured sphere in a Cornell box",

@@ -220,179 +220,25 @@ V4R_DEV uint32_t class_base(const Queues &Q, uint32_t seg, int cls) {
 // leaves that lanes have parked.  A hit is ranked within its shading class in LDS; when the chunk is
 // done the workgroup reserves its slots in each class queue with one global atomic per class and
 // copies the ray + hit records there.  (Letting a lane start its next ray while its neighbours are
-// still inside the previous one was measured and lost 10-15 %: the extra votes and the divergent
-// fetch cost more than the idle lanes they remove.)
-// Variant of k_trace in which a lane takes its next ray as soon as its current one is finished.  Rays
-// of the chunk are handed out through a ticket counter in LDS; every lane keeps the ray after its
-// current one already loaded in registers, so starting it costs no memory latency.  A finished ray
-// only stores (t, prim, u, v); class ranking, misses and the copy into the class queues are done for
-// the whole chunk at its end, by all lanes.
-template <bool COUNT, int RAYS_PER_THREAD>
-__global__ __launch_bounds__(BLOCK) void k_trace_dyn(SceneDev S, Queues Q, uint32_t seg) {
+// still inside the previous one -- rays handed out by an LDS ticket counter, the next ray kept
+// preloaded in registers -- was measured: it removes 12 % of the wave-level node steps on the sphere
+// scenes and 46 % on the bunny scene, but its extra votes and low-occupancy set-up code made all but
+// the bunny scene 5-20 % slower, so rays are assigned statically.)
+#ifndef V4R_TRACE_MIN_WAVES
+#define V4R_TRACE_MIN_WAVES 1
+#endif
+template <bool COUNT, int RAYS_PER_THREAD, bool MEDIA>
+__global__ __launch_bounds__(BLOCK, V4R_TRACE_MIN_WAVES) void k_trace(SceneDev S, Queues Q, uint32_t seg) {
     __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
-    __shared__ uint32_t s_base, s_next;
-    __shared__ uint32_t s_cnt[CLS_COUNT];
-    __shared__ uint16_t s_where[RAYS_PER_THREAD * BLOCK];  // per ray of the chunk: class << 12 | rank among the chunk's hits of that class
-    static_assert(RAYS_PER_THREAD * BLOCK <= 4096, "rank field of s_where is 12 bits");
-    Stack st;
-    st.lds = lds_stack + threadIdx.x;
-    st.stride = BLOCK;
-    st.spill = Q.spill + (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    st.spill_stride = Q.spill_stride;
-    st.sp = 0;
-    SegCtr *ctr = Q.ctr + seg;
-    const uint32_t n_in = rays_in(Q, seg);
-    float4 *const *rq = Q.ray[seg & 1u];
-    TraceCounters cnt;
-    uint32_t n_traced = 0;
-    bool started = false;
-    const uint32_t per_thread = min((uint32_t)RAYS_PER_THREAD, max(1u, (n_in + gridDim.x * BLOCK - 1u) / (gridDim.x * BLOCK)));
-    const uint32_t chunk = per_thread * BLOCK;
-    const bool single = S.n_nodes == 0;  // one primitive, no BVH (bvh.rs:218-224)
-    const uint32_t lane = lane_id();
-    while (true) {
-        if (threadIdx.x == 0) {
-            s_base = started ? gridDim.x * chunk + atomicAdd(&ctr->trace_cursor, chunk) : blockIdx.x * chunk;
-            s_next = 0;
-        }
-        if (threadIdx.x < CLS_COUNT) s_cnt[threadIdx.x] = 0;
-        started = true;
-        __syncthreads();
-        const uint32_t base = s_base;
-        if (base >= n_in) break;
-        const uint32_t n_here = min(chunk, n_in - base);
-
-        bool have = false, next_valid = false;
-        uint32_t cur_k = 0, next_k = 0;
-        V3 o = v3(0, 0, 0), d = v3(1, 0, 0), inv = v3(1, 1, 1), next_o = o, next_d = d;
-        Best best;
-        best.t = V4R_INF;
-        best.prim = NO_PRIM;
-        best.u = best.v = 0.0f;
-        Trav T;
-        T.clear();
-        bool want = true;  // this lane wants a ticket
-        while (true) {
-            // ---- lanes without a ray start the one they hold ready ...
-            if (!have && next_valid) {
-                o = next_o;
-                d = next_d;
-                cur_k = next_k;
-                inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                best.t = V4R_INF;
-                best.prim = NO_PRIM;
-                best.u = best.v = 0.0f;
-                st.sp = 0;
-                have = true;
-                next_valid = false;
-                want = true;
-                if (COUNT) n_traced++;
-                if (single) {
-                    T.clear();
-                    if (S.n_prims) {
-                        if (COUNT) cnt.prims++;
-                        consider(S, 0, o, d, best);
-                    }
-                } else {
-                    T.start();
-                }
-            }
-            // ---- ... and load the one after it (one LDS atomic per wave)
-            unsigned long long m_want = __ballot(want);
-            if (m_want != 0ull) {
-                uint32_t t0 = 0;
-                if (lane == (uint32_t)__ffsll((long long)m_want) - 1u) t0 = atomicAdd(&s_next, (uint32_t)__popcll(m_want));
-                t0 = __shfl(t0, __ffsll((long long)m_want) - 1);
-                if (want) {
-                    uint32_t k = t0 + (uint32_t)__popcll(m_want & ((1ull << lane) - 1ull));
-                    want = false;
-                    if (k < n_here) {
-                        float4 a = rq[0][base + k];
-                        float2 b = *reinterpret_cast<const float2 *>(&rq[1][base + k]);
-                        next_o = v3(a.x, a.y, a.z);
-                        next_d = v3(a.w, b.x, b.y);
-                        next_k = k;
-                        next_valid = true;
-                    }
-                }
-                if (__ballot(!have && next_valid) != 0ull) continue;  // first round of the chunk: nothing to trace yet
-            }
-            if (__ballot(have) == 0ull) break;  // the chunk has no rays left for this wave
-            // ---- interior nodes, until enough lanes wait for another phase
-            while (true) {
-                bool stepping = have && T.stepping();
-                unsigned long long m_step = __ballot(stepping);
-                if (m_step == 0ull) break;
-                bool finished = have && T.node == TRAV_NONE && !T.parked();
-                bool waiting = (have && T.parked()) || (finished && next_valid);
-                unsigned long long m_wait = __ballot(waiting);
-                if (m_wait != 0ull && __popcll(m_wait) * V4R_VOTE_DEN >= (__popcll(m_wait) + __popcll(m_step)) * V4R_VOTE_NUM) break;
-                if (COUNT) cnt.wave_steps++;
-                if (stepping) trav_step<COUNT>(S, o, inv, st, best, T, cnt);
-            }
-            // ---- parked leaves
-            if (__ballot(have && T.parked()) != 0ull) trav_leaves<COUNT>(S, o, d, st, best, T, cnt);
-            // ---- finished rays leave their result
-            if (have && T.node == TRAV_NONE && !T.parked()) {
-                Q.hitd[base + cur_k] = make_float4(best.t, __uint_as_float(best.prim), best.u, best.v);
-                have = false;
-            }
-        }
-        __syncthreads();  // also makes the hitd records of the chunk visible to the whole workgroup
-#pragma unroll 1
-        for (uint32_t k = threadIdx.x; k < n_here; k += BLOCK) {
-            uint32_t i = base + k;
-            uint32_t prim = __float_as_uint(Q.hitd[i].y);
-            uint32_t w = 0xFFFFu;
-            if (prim != NO_PRIM) {
-                uint32_t cls = S.prim_info[prim] >> 24;
-                w = (cls << 12) | atomicAdd(&s_cnt[cls], 1u);
-            } else {  // renderer.rs:184: a miss takes the background colour
-                float4 bb = rq[1][i], c = rq[2][i];
-                Q.rad[__float_as_uint(c.y)] = make_float4(bb.z * S.bg[0], bb.w * S.bg[1], c.x * S.bg[2], 0.0f);
-            }
-            s_where[k] = (uint16_t)w;
-        }
-        __syncthreads();
-        if (threadIdx.x < CLS_COUNT) {
-            uint32_t n = s_cnt[threadIdx.x];
-            s_cnt[threadIdx.x] = n ? atomicAdd(&ctr->hit_count[threadIdx.x], n) : 0u;
-        }
-        __syncthreads();
-#pragma unroll 1
-        for (uint32_t k = threadIdx.x; k < n_here; k += BLOCK) {
-            uint32_t i = base + k;
-            uint32_t w = s_where[k];
-            if (w != 0xFFFFu) {
-                uint32_t c = w >> 12, idx = s_cnt[c] + (w & 0xFFFu);
-                Q.hit[c][0][idx] = rq[0][i];
-                Q.hit[c][1][idx] = rq[1][i];
-                Q.hit[c][2][idx] = rq[2][i];
-                Q.hit[c][3][idx] = Q.hitd[i];
-            }
-        }
-        __syncthreads();
-    }
-    if (COUNT) {
-        unsigned long long s = wave_sum(n_traced), n = wave_sum(cnt.nodes), q = wave_sum(cnt.prims);
-        if (lane_id() == 0) {
-            atomicAdd(&Q.stats[0], s);
-            atomicAdd(&Q.stats[1], n);
-            atomicAdd(&Q.stats[2], q);
-            atomicAdd(&Q.stats[6], (unsigned long long)cnt.wave_steps);
-            atomicAdd(&Q.stats[7], (unsigned long long)cnt.wave_leaves);
-        }
-    }
-}
-
-template <bool COUNT, int RAYS_PER_THREAD>
-__global__ __launch_bounds__(BLOCK) void k_trace(SceneDev S, Queues Q, uint32_t seg) {
-    __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
+#ifdef V4R_LDS_PAD
+    __shared__ uint32_t lds_pad[V4R_LDS_PAD / 4];
+    if (seg == 0xFFFFFFFFu) lds_pad[threadIdx.x] = 1, Q.stats[threadIdx.x] = lds_pad[threadIdx.x ^ 1];
+#endif
     __shared__ uint32_t s_base;
     __shared__ uint32_t s_cnt[CLS_COUNT];
     __shared__ uint32_t s_where[RAYS_PER_THREAD * BLOCK];  // per ray of the chunk: class << 16 | rank among the chunk's hits of that class
     Stack st;
-    st.lds = lds_stack + threadIdx.x;
+    st.lds = (lds_uint2 *)lds_stack + threadIdx.x;
     st.stride = BLOCK;
     st.spill = Q.spill + (size_t)blockIdx.x * BLOCK + threadIdx.x;
     st.spill_stride = Q.spill_stride;
@@ -427,7 +273,12 @@ __global__ __launch_bounds__(BLOCK) void k_trace(SceneDev S, Queues Q, uint32_t 
                 V3 o = v3(a.x, a.y, a.z), d = v3(a.w, b.x, b.y);
                 Best best;
                 if (COUNT && active) n_traced++;
-                traverse<COUNT>(S, o, d, active, st, best, cnt);
+                // the random stream of the segment, needed only if the ray meets a constant medium
+                auto key = [&]() {
+                    float4 c = rq[2][ii];
+                    return segment_key(__float_as_uint(c.z), __float_as_uint(c.w), seg);
+                };
+                traverse<COUNT, MEDIA>(S, o, d, active, st, best, cnt, key);
                 uint32_t w = 0xFFFFFFFFu;
                 if (active) {
                     if (best.prim != NO_PRIM) {
@@ -636,11 +487,14 @@ __global__ __launch_bounds__(BLOCK) void k_tonemap(const float *accum, size_t n,
 }
 
 // Closest hit of explicit rays (or of the deterministic primary rays when origin == nullptr).
+// Ray i draws the free path of a constant medium from the stream of path (seed, pass 0, pixel i);
+// the deterministic primary rays use key 0.
+template <bool MEDIA>
 __global__ __launch_bounds__(BLOCK) void k_trace_rays(SceneDev S, Queues Q, uint32_t n, const float *origin, const float *dir,
-                                                      uint32_t *prim_out, float *t_out) {
+                                                      uint32_t seed_lo, uint32_t seed_hi, uint32_t *prim_out, float *t_out) {
     __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
     Stack st;
-    st.lds = lds_stack + threadIdx.x;
+    st.lds = (lds_uint2 *)lds_stack + threadIdx.x;
     st.stride = BLOCK;
     st.spill = Q.spill + (size_t)blockIdx.x * BLOCK + threadIdx.x;
     st.spill_stride = Q.spill_stride;
@@ -661,7 +515,13 @@ __global__ __launch_bounds__(BLOCK) void k_trace_rays(SceneDev S, Queues Q, uint
             }
         }
         Best best;
-        traverse<false>(S, o, d, valid, st, best, cnt);
+        auto key = [&]() {
+            if (!origin) return 0u;
+            uint32_t k0, k1;
+            path_key(seed_lo, seed_hi, 0u, i, k0, k1);
+            return segment_key(k0, k1, 0u);
+        };
+        traverse<false, MEDIA>(S, o, d, valid, st, best, cnt, key);
         if (valid) {
             prim_out[i] = best.prim;
             t_out[i] = best.t;
@@ -718,6 +578,7 @@ struct v4r_renderer {
     double trace_ms = 0.0;
     uint64_t trace_launches = 0;
     bool has_class[CLS_COUNT] = {false, false, false, false, false, false};
+    bool has_media = false;  // selects the kernels that carry the constant-medium test
     size_t ctr_bytes = 0;
 
     template <class T>
@@ -862,7 +723,6 @@ int validate(const v4r_scene_desc *d, uint32_t &depth_out) {
         if ((d->prims[d->lights[i]].type & V4R_PRIM_TYPE_MASK) == V4R_PRIM_MEDIUM)
             return set_error(V4R_E_INVALID, "a constant medium cannot be a light");
     }
-    if (d->n_media != 0) return set_error(V4R_E_UNSUPPORTED, "constant media are not implemented on the device path yet");
     return V4R_OK;
 }
 
@@ -932,6 +792,7 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     if (int rc = r->upload(&S.perlin_perm, pperm.data(), pperm.size())) return rc;
     if (int rc = r->upload(&S.lights, d->lights, (size_t)d->n_lights)) return rc;
     S.n_nodes = d->n_nodes;
+    r->has_media = d->n_media != 0;
     S.n_prims = d->n_prims;
     S.n_lights = d->n_lights;
     S.flags = d->flags;
@@ -955,7 +816,8 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     if (r->batch_passes >= 16u) r->batch_passes &= ~15u;  // whole groups of passes for the tiled ray order of k_raygen
     uint32_t n_pipes = 3;
     if (const char *env = std::getenv("V4R_PIPES")) n_pipes = (uint32_t)std::max(1, std::min(4, std::atoi(env)));
-    r->grid_trace = std::max(grid_for(k_trace<false, TRACE_RAYS_PER_THREAD>, n_cu), grid_for(k_trace_rays, n_cu));
+    r->grid_trace = r->has_media ? std::max(grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, true>, n_cu), grid_for(k_trace_rays<true>, n_cu))
+                                 : std::max(grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, false>, n_cu), grid_for(k_trace_rays<false>, n_cu));
     r->grid_shade = (uint32_t)n_cu * 8u;
     r->grid_stream = (uint32_t)n_cu * 8u;
     uint32_t spill_depth = bvh_depth > (uint32_t)LDS_DEPTH ? bvh_depth - LDS_DEPTH : 0;
@@ -992,6 +854,18 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     if (int rc = r->alloc(&r->tonemap_buf, (size_t)r->npix * 3)) return rc;
     HIP_TRY(hipDeviceSynchronize());
     return V4R_OK;
+}
+
+void launch_trace(v4r_renderer *r, Pipe &pipe, uint32_t seg) {
+    dim3 grid(r->grid_trace), block(BLOCK);
+    constexpr int R = TRACE_RAYS_PER_THREAD;
+    if (r->has_media) {
+        if (r->counting) hipLaunchKernelGGL((k_trace<true, R, true>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg);
+        else hipLaunchKernelGGL((k_trace<false, R, true>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg);
+    } else {
+        if (r->counting) hipLaunchKernelGGL((k_trace<true, R, false>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg);
+        else hipLaunchKernelGGL((k_trace<false, R, false>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg);
+    }
 }
 
 template <int CLS>
@@ -1036,12 +910,7 @@ int run_batch(v4r_renderer *r, Pipe &pipe, uint64_t seed, uint32_t first_pass, u
             ev1 = r->ev_pool[r->ev_used++];
             HIP_TRY(hipEventRecord(ev0, pipe.stream));
         }
-        static const int dyn = getenv("V4R_TRACE_DYN") ? atoi(getenv("V4R_TRACE_DYN")) : 0;
-        if (dyn) {
-            if (r->counting) hipLaunchKernelGGL((k_trace_dyn<true, 8>), dim3(r->grid_trace), dim3(BLOCK), 0, pipe.stream, r->S, pipe.Q, seg);
-            else hipLaunchKernelGGL((k_trace_dyn<false, 8>), dim3(r->grid_trace), dim3(BLOCK), 0, pipe.stream, r->S, pipe.Q, seg);
-        } else if (r->counting) hipLaunchKernelGGL((k_trace<true, TRACE_RAYS_PER_THREAD>), dim3(r->grid_trace), dim3(BLOCK), 0, pipe.stream, r->S, pipe.Q, seg);
-        else hipLaunchKernelGGL((k_trace<false, TRACE_RAYS_PER_THREAD>), dim3(r->grid_trace), dim3(BLOCK), 0, pipe.stream, r->S, pipe.Q, seg);
+        launch_trace(r, pipe, seg);
         if (r->profiling) HIP_TRY(hipEventRecord(ev1, pipe.stream));
         launch_shade<CLS_LIGHT>(r, pipe, seg);
         launch_shade<CLS_LAMBERT>(r, pipe, seg);
@@ -1182,7 +1051,8 @@ int v4r_tonemap_u8(v4r_renderer *r, uint32_t n_passes, uint8_t *host_rgb) {
     return V4R_OK;
 }
 
-static int trace_common(v4r_renderer *r, uint32_t n, const float *host_origin, const float *host_dir, uint32_t *host_prim_id, float *host_t) {
+static int trace_common(v4r_renderer *r, uint32_t n, const float *host_origin, const float *host_dir, uint64_t seed, uint32_t *host_prim_id,
+                        float *host_t) {
     HIP_TRY(hipSetDevice(r->device));
     if (n == 0) return V4R_OK;
     float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr;
@@ -1203,7 +1073,12 @@ static int trace_common(v4r_renderer *r, uint32_t n, const float *host_origin, c
     if (e == hipSuccess) e = hipMalloc((void **)&d_t, (size_t)n * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&d_p, (size_t)n * sizeof(uint32_t));
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_trace_rays, dim3(r->grid_trace), dim3(BLOCK), 0, r->stream, r->S, r->pipes[0].Q, n, d_o, d_d, d_p, d_t);
+        if (r->has_media)
+            hipLaunchKernelGGL(k_trace_rays<true>, dim3(r->grid_trace), dim3(BLOCK), 0, r->stream, r->S, r->pipes[0].Q, n, d_o, d_d,
+                               (uint32_t)seed, (uint32_t)(seed >> 32), d_p, d_t);
+        else
+            hipLaunchKernelGGL(k_trace_rays<false>, dim3(r->grid_trace), dim3(BLOCK), 0, r->stream, r->S, r->pipes[0].Q, n, d_o, d_d,
+                               (uint32_t)seed, (uint32_t)(seed >> 32), d_p, d_t);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
@@ -1216,15 +1091,14 @@ static int trace_common(v4r_renderer *r, uint32_t n, const float *host_origin, c
 
 int v4r_trace_primary(v4r_renderer *r, uint32_t *host_prim_id, float *host_t) {
     if (!r) return set_error(V4R_E_INVALID, "NULL renderer");
-    return trace_common(r, r->npix, nullptr, nullptr, host_prim_id, host_t);
+    return trace_common(r, r->npix, nullptr, nullptr, 0, host_prim_id, host_t);
 }
 
 int v4r_trace_rays(v4r_renderer *r, uint32_t n, const float *host_origin, const float *host_dir, uint64_t seed,
                    uint32_t *host_prim_id, float *host_t) {
-    (void)seed;  // keys the constant-medium draw once media run on the device
     if (!r) return set_error(V4R_E_INVALID, "NULL renderer");
     if (n && (!host_origin || !host_dir)) return set_error(V4R_E_INVALID, "NULL ray arrays");
-    return trace_common(r, n, host_origin, host_dir, host_prim_id, host_t);
+    return trace_common(r, n, host_origin, host_dir, seed, host_prim_id, host_t);
 }
 
 int v4r_stats_enable(v4r_renderer *r, int on) {

@@ -148,22 +148,82 @@ struct Best {
     float u, v;  // triangle barycentrics
 };
 
-// One primitive against the ray over [EPSILON, +inf) (renderer.rs:167) with the closest-hit rule
-// of renderer.rs:174 (strictly smaller t wins; equal t keeps the lowest index).
-V4R_DEV void consider(const SceneDev &S, uint32_t prim_index, V3 o, V3 d, Best &best) {
-    Prim pr = load_prim(S.prims, prim_index);
+// Distance to a sphere / rectangle / triangle record, through its own affine transform if it has one
+// (TransformHittable::hit, transform.rs:64-95).  t is in the caller's space.
+V4R_DEV bool solid_t(const SceneDev &S, const Prim &pr, V3 o, V3 d, float t_min, float t_max, float &t, float &u, float &v) {
     float nrm = 1.0f;
     uint32_t xf = pr.xform();
-    if (xf != V4R_NO_XFORM) to_object(S.xforms + 24 * (size_t)xf, o, d, nrm);
-    float t_min = EPSILON * nrm, t_max = V4R_INF * nrm;
-    float t = 0.0f, u = 0.0f, v = 0.0f, det;
+    if (xf != V4R_NO_XFORM) {
+        to_object(S.xforms + 24 * (size_t)xf, o, d, nrm);
+        t_min = t_min * nrm;
+        t_max = t_max * nrm;
+    }
+    float det;
     bool hit;
     uint32_t kind = pr.type() & V4R_PRIM_TYPE_MASK;
+    t = 0.0f;
     if (kind == V4R_PRIM_SPHERE) hit = sphere_t(pr, o, d, t_min, t_max, t);
     else if (kind == V4R_PRIM_TRIANGLE) hit = tri_t(pr, o, d, t_min, t_max, t, u, v, det);
     else if (kind <= V4R_PRIM_ZX_RECT) hit = rect_t(pr, o, d, t_min, t_max, t);
     else hit = false;
     if (xf != V4R_NO_XFORM) t = t / nrm;  // transform.rs:90
+    return hit;
+}
+
+// HittableGroup::hit over the boundary of a medium (hittables/group.rs:58-67): the nearest boundary
+// hit inside [t_min, t_max].
+V4R_DEV bool boundary_t(const SceneDev &S, uint32_t first, uint32_t count, V3 o, V3 d, float t_min, float t_max, float &t) {
+    bool any = false;
+    float closest = t_max;
+    for (uint32_t i = 0; i < count; ++i) {
+        Prim bp = load_prim(S.medium_prims, first + i);
+        float ti, u, v;
+        if (solid_t(S, bp, o, d, t_min, closest, ti, u, v)) {
+            closest = ti;
+            any = true;
+        }
+    }
+    t = closest;
+    return any;
+}
+
+// ConstantMedium::hit, hittable/constant_medium.rs:40-85: entry and exit of the boundary along the
+// whole line, an exponential free path inside; `key()` yields the segment key of the ray, asked for
+// only when a medium is actually tested.
+template <class KeyFn>
+V4R_DEV bool medium_t(const SceneDev &S, const Prim &pr, uint32_t prim_index, V3 o, V3 d, float t_min, float t_max, float &t, KeyFn key) {
+    uint4 m = S.media[pr.aux()];  // first, count, -1/density
+    float t1, t2;
+    if (!boundary_t(S, m.x, m.y, o, d, -V4R_INF, V4R_INF, t1)) return false;
+    if (!boundary_t(S, m.x, m.y, o, d, t1 + EPSILON, V4R_INF, t2)) return false;
+    float lo = fmaxf(t1, t_min), hi = fminf(t2, t_max);
+    if (!(lo < hi)) return false;
+    lo = fmaxf(lo, 0.0f);
+    float distance_inside = hi - lo;
+    float hit_distance = __uint_as_float(m.z) * logf(draw(key(), DIM_MEDIUM + (prim_index & 31u)));
+    if (!(hit_distance <= distance_inside)) return false;
+    t = t1 + hit_distance;
+    return true;
+}
+
+// One primitive against the ray over [EPSILON, +inf) (renderer.rs:167) with the closest-hit rule
+// of renderer.rs:174 (strictly smaller t wins; equal t keeps the lowest index).
+// MEDIA = false compiles the constant-medium branch out (scenes without media): the branch holds a
+// second ray in object space and a loop over boundary records, which costs ~40 registers.
+template <bool MEDIA, class KeyFn>
+V4R_DEV void consider(const SceneDev &S, uint32_t prim_index, V3 o, V3 d, Best &best, KeyFn key) {
+    Prim pr = load_prim(S.prims, prim_index);
+    float t, u = 0.0f, v = 0.0f;
+    bool hit;
+    if (MEDIA && (pr.type() & V4R_PRIM_TYPE_MASK) == V4R_PRIM_MEDIUM) {
+        float nrm = 1.0f;
+        uint32_t xf = pr.xform();
+        if (xf != V4R_NO_XFORM) to_object(S.xforms + 24 * (size_t)xf, o, d, nrm);
+        hit = medium_t(S, pr, prim_index, o, d, EPSILON * nrm, V4R_INF * nrm, t, key);
+        if (xf != V4R_NO_XFORM) t = t / nrm;
+    } else {
+        hit = solid_t(S, pr, o, d, EPSILON, V4R_INF, t, u, v);
+    }
     if (hit && (t < best.t || (t == best.t && prim_index < best.prim))) {
         best.t = t;
         best.prim = prim_index;
@@ -174,22 +234,41 @@ V4R_DEV void consider(const SceneDev &S, uint32_t prim_index, V3 o, V3 d, Best &
 
 // Stack of the traversal: the first LDS_DEPTH entries of each lane live in LDS (conflict-free:
 // entry e of thread t sits at [e][t]); deeper entries spill to a per-thread slab in HBM.
-constexpr int LDS_DEPTH = 12;
+#ifndef V4R_LDS_DEPTH
+#define V4R_LDS_DEPTH 12
+#endif
+constexpr int LDS_DEPTH = V4R_LDS_DEPTH;
+// The LDS part is addressed through an LDS-typed pointer: through a generic one the compiler merges
+// the two halves of push/pop into flat loads and stores, which are slower and wait on both counters.
+typedef __attribute__((address_space(3))) uint2 lds_uint2;
 struct Stack {
-    uint2 *lds;        // this thread's column: lds[e * block_dim]
+    lds_uint2 *lds;    // this thread's column: lds[e * block_dim]
     uint32_t stride;   // block_dim
     uint2 *spill;      // this thread's column in the global slab: spill[e * spill_stride]
     size_t spill_stride;
     int sp;
     __device__ __forceinline__ void push(uint32_t node, float entry) {
         uint2 v = make_uint2(node, __float_as_uint(entry));
-        if (sp < LDS_DEPTH) lds[(uint32_t)sp * stride] = v;
-        else spill[(size_t)(sp - LDS_DEPTH) * spill_stride] = v;
+        if (sp < LDS_DEPTH) {
+            lds_uint2 *p = lds + (uint32_t)sp * stride;
+            p->x = v.x;
+            p->y = v.y;
+        } else {
+            spill[(size_t)(sp - LDS_DEPTH) * spill_stride] = v;
+        }
         ++sp;
     }
     __device__ __forceinline__ uint2 pop() {
         --sp;
-        return sp < LDS_DEPTH ? lds[(uint32_t)sp * stride] : spill[(size_t)(sp - LDS_DEPTH) * spill_stride];
+        uint2 v;
+        if (sp < LDS_DEPTH) {
+            const lds_uint2 *p = lds + (uint32_t)sp * stride;
+            v.x = p->x;
+            v.y = p->y;
+        } else {
+            v = spill[(size_t)(sp - LDS_DEPTH) * spill_stride];
+        }
+        return v;
     }
 };
 
@@ -268,8 +347,8 @@ V4R_DEV void trav_step(const SceneDev &S, V3 o, V3 inv, Stack &st, const Best &b
 
 // Intersect the parked leaves of every lane of the wave (child 0's before child 1's), then settle
 // which node each of those lanes visits next.  Called by the whole wave.
-template <bool COUNT>
-V4R_DEV void trav_leaves(const SceneDev &S, V3 o, V3 d, Stack &st, Best &best, Trav &T, TraceCounters &cnt) {
+template <bool COUNT, bool MEDIA, class KeyFn>
+V4R_DEV void trav_leaves(const SceneDev &S, V3 o, V3 d, Stack &st, Best &best, Trav &T, TraceCounters &cnt, KeyFn key) {
     bool parked = T.parked();
 #pragma unroll 1
     for (int k = 0; k < 2; ++k) {
@@ -280,7 +359,7 @@ V4R_DEV void trav_leaves(const SceneDev &S, V3 o, V3 d, Stack &st, Best &best, T
         if (COUNT) cnt.wave_leaves++;
         if (go) {
             if (COUNT) cnt.prims++;
-            consider(S, prim, o, d, best);
+            consider<MEDIA>(S, prim, o, d, best, key);
         }
     }
     if (parked) {
@@ -292,8 +371,8 @@ V4R_DEV void trav_leaves(const SceneDev &S, V3 o, V3 d, Stack &st, Best &best, T
 
 // Closest hit of one ray per lane.  Must be called by every lane of the wave; lanes with
 // active == false only take part in the votes.
-template <bool COUNT>
-V4R_DEV void traverse(const SceneDev &S, V3 o, V3 d, bool active, Stack &st, Best &best, TraceCounters &cnt) {
+template <bool COUNT, bool MEDIA, class KeyFn>
+V4R_DEV void traverse(const SceneDev &S, V3 o, V3 d, bool active, Stack &st, Best &best, TraceCounters &cnt, KeyFn key) {
     best.t = V4R_INF;
     best.prim = NO_PRIM;
     best.u = best.v = 0.0f;
@@ -301,7 +380,7 @@ V4R_DEV void traverse(const SceneDev &S, V3 o, V3 d, bool active, Stack &st, Bes
     if (S.n_nodes == 0) {  // single shape: tested without any box (bvh.rs:218-224)
         if (active) {
             if (COUNT) cnt.prims++;
-            consider(S, 0, o, d, best);
+            consider<MEDIA>(S, 0, o, d, best, key);
         }
         return;
     }
@@ -319,7 +398,7 @@ V4R_DEV void traverse(const SceneDev &S, V3 o, V3 d, bool active, Stack &st, Bes
             if (COUNT) cnt.wave_steps++;
             if (T.stepping()) trav_step<COUNT>(S, o, inv, st, best, T, cnt);
         }
-        if (__ballot(T.parked()) != 0ull) trav_leaves<COUNT>(S, o, d, st, best, T, cnt);
+        if (__ballot(T.parked()) != 0ull) trav_leaves<COUNT, MEDIA>(S, o, d, st, best, T, cnt, key);
         if (__ballot(T.node != TRAV_NONE) == 0ull) break;
     }
 }

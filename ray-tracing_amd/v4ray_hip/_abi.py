@@ -189,7 +189,8 @@ def device_lib():
     global _dev
     if _dev is not None:
         return _dev
-    path = os.path.join(LIB_DIR, "libv4ray_hip.so")
+    # V4R_DEVICE_LIB selects another build of the same library (kernel tuning experiments)
+    path = os.environ.get("V4R_DEVICE_LIB") or os.path.join(LIB_DIR, "libv4ray_hip.so")
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: the HIP library must be built before rendering "
                            f"(`make -C ray-tracing_amd hip`); there is no CPU fallback")

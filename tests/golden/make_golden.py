@@ -22,7 +22,7 @@ import oracle  # noqa: E402
 from v4ray_hip import load_image, scenes  # noqa: E402
 
 PRIMARY_SIZE = {"c1": (64, 64), "c2": (96, 54), "c3": (64, 64), "c4": (96, 54), "c5": (96, 54)}
-IMAGE_SIZE = {"c2": (128, 72), "c3": (96, 96), "c4": (128, 72), "c5": (128, 72)}
+IMAGE_SIZE = {"c1": (96, 96), "c2": (128, 72), "c3": (96, 96), "c4": (128, 72), "c5": (128, 72)}
 IMAGE_SPP = 1024
 SEED = 0x5EED
 

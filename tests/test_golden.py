@@ -12,7 +12,7 @@ from v4ray_hip import load_image, scenes
 HERE = os.path.dirname(os.path.abspath(__file__))
 G = np.load(os.path.join(HERE, "golden", "golden.npz"))
 PRIMARY_SIZE = {"c1": (64, 64), "c2": (96, 54), "c3": (64, 64), "c4": (96, 54), "c5": (96, 54)}
-IMAGE_SIZE = {"c2": (128, 72), "c3": (96, 96), "c4": (128, 72), "c5": (128, 72)}
+IMAGE_SIZE = {"c1": (96, 96), "c2": (128, 72), "c3": (96, 96), "c4": (128, 72), "c5": (128, 72)}
 MISS = 0xFFFFFFFF
 
 
@@ -58,7 +58,7 @@ def test_decoded_assets_are_stable():
 
 # ---- GPU ------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["c2", "c3", "c4", "c5"])
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c4", "c5"])
 def test_device_matches_golden_primary_hits(name):
     from v4ray_hip import Renderer
     s = scenes.load(name, *PRIMARY_SIZE[name])
@@ -74,7 +74,7 @@ def test_device_matches_golden_primary_hits(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["c2", "c3", "c4", "c5"])
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c4", "c5"])
 def test_device_converged_image_psnr(name):
     """>= 1024 spp: PSNR >= 40 dB against the oracle's render of the same scene (same random streams), and a
     render from different streams agrees up to Monte-Carlo noise."""

@@ -9,7 +9,7 @@ from v4ray_hip import (Dielectric, Lambertian, Metal, PerspectiveCameraParam, Re
 pytestmark = pytest.mark.gpu
 MISS = 0xFFFFFFFF
 
-SMALL = {"c2": (256, 144), "c3": (160, 160), "c4": (256, 144), "c5": (256, 144)}
+SMALL = {"c1": (160, 160), "c2": (256, 144), "c3": (160, 160), "c4": (256, 144), "c5": (256, 144)}
 
 
 def make(name, **kw):
@@ -32,7 +32,7 @@ def check_primary(r):
     return same.mean(), rel.max()
 
 
-@pytest.mark.parametrize("name", ["c2", "c3", "c4", "c5"])
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c4", "c5"])
 def test_primary_hits_match_oracle(name):
     scene, r = make(name)
     check_primary(r)
@@ -62,7 +62,7 @@ def scene_bounds(desc):
     return lo, hi
 
 
-@pytest.mark.parametrize("name", ["c2", "c3", "c4", "c5"])
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c4", "c5"])
 def test_random_rays_match_oracle(name):
     """Rays with random origins inside the scene's bounding box and uniformly random directions."""
     scene, r = make(name)
@@ -74,8 +74,8 @@ def test_random_rays_match_oracle(name):
     o = (lo + (hi - lo) * rng.random((n, 3), dtype=np.float32)).astype(np.float32)
     v = rng.normal(size=(n, 3)).astype(np.float32)
     v = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
-    prim_d, t_d = r.trace_rays(o, v)
-    prim_o, t_o = oracle.trace_rays(r.desc, o, v)
+    prim_d, t_d = r.trace_rays(o, v, seed=99)   # the seed keys the free-path draws of constant media (c1)
+    prim_o, t_o = oracle.trace_rays(r.desc, o, v, seed=99)
     same = prim_d == prim_o
     hit = same & (prim_o != MISS)
     rel = np.abs(t_d[hit] - t_o[hit]) / np.abs(t_o[hit])
@@ -85,7 +85,7 @@ def test_random_rays_match_oracle(name):
     r.close()
 
 
-@pytest.mark.parametrize("name,spp", [("c2", 4), ("c3", 8), ("c5", 4), ("c4", 2)])
+@pytest.mark.parametrize("name,spp", [("c1", 4), ("c2", 4), ("c3", 8), ("c5", 4), ("c4", 2)])
 def test_render_matches_oracle_per_pixel(name, spp):
     """Oracle and device draw the same random numbers, so they follow the same paths: almost every
     pixel agrees to rounding; the rest are paths where a rounding difference flipped a discrete
@@ -101,6 +101,33 @@ def test_render_matches_oracle_per_pixel(name, spp):
     close = float((diff < 2e-3).mean())
     print(f"{name}: pixels within 2e-3: {close:.4f}; mean device {img_d.mean():.6f} oracle {img_o.mean():.6f}")
     assert close >= 0.90, close
+    assert abs(img_d.mean() - img_o.mean()) <= 0.01 * abs(img_o.mean()) + 1e-6
+    r.close()
+
+
+def test_constant_medium_free_path_on_device():
+    """constant_medium.rs:40-85 through the device traversal: a ray through a unit fog sphere of density 2
+    is scattered iff -ln(U)/2 <= 2 (the chord), at t = entry + that distance; U is the draw the oracle
+    makes for the same (seed, ray index)."""
+    from v4ray_hip import ConstantMedium, Isotropic
+    scene = Scene((0, 0, 0))
+    scene.add(ConstantMedium(Sphere((0, 0, 0), 1.0), 2.0), Isotropic(SolidColor((1, 1, 1))))
+    scene.add(Sphere((0, 0, 3), 1.0), Lambertian(SolidColor((0.5, 0.5, 0.5))))
+    r = Renderer(RendererParam(16, 16, max_depth=4), PerspectiveCameraParam((0, 0, -5), (0, 0, 0), 40.0), scene)
+    n = 4000
+    o = np.tile(np.float32([0, 0, -5]), (n, 1))
+    v = np.tile(np.float32([0, 0, 1]), (n, 1))
+    prim_d, t_d = r.trace_rays(o, v, seed=5)
+    prim_o, t_o = oracle.trace_rays(r.desc, o, v, seed=5)
+    assert np.array_equal(prim_d, prim_o)
+    fog = prim_d == 0
+    assert abs(fog.mean() - (1 - np.exp(-4.0))) < 0.02       # P(scatter inside a chord of length 2 at density 2)
+    assert (prim_d[~fog] == 1).all() and np.allclose(t_d[~fog], 7.0, rtol=1e-6)
+    assert np.allclose(t_d[fog], t_o[fog], rtol=1e-5) and (t_d[fog] >= 4.0).all() and (t_d[fog] <= 6.0 + 1e-4).all()
+    # the same scene rendered: isotropic scattering out of the fog, same paths as the oracle
+    r.render_passes(8)
+    img_d, _ = r.read_accumulator()
+    img_o, _ = oracle.render(r.desc, 8, seed=r.seed)
     assert abs(img_d.mean() - img_o.mean()) <= 0.01 * abs(img_o.mean()) + 1e-6
     r.close()
 
@@ -229,6 +256,3 @@ def test_errors_are_status_codes():
     bad.n_nodes -= 1
     assert lib.v4r_renderer_create(C.byref(bad), 0, C.byref(h)) == -1
     assert lib.v4r_renderer_create(desc, 99, C.byref(h)) == -2
-    media = scenes.load("c1", 32, 32)
-    with pytest.raises(V4RayError, match="media"):
-        Renderer(media.renderer_param, media.camera_param, media)
