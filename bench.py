@@ -167,6 +167,15 @@ def main():
                     "lane_utilisation_prim_test": round(stats["prims"] / max(1, 64 * stats["wave_leaf_steps"]), 3),
                     "wave_node_steps_per_wave_ray": round(64 * stats["wave_node_steps"] / stats["segments"], 2),
                     "wave_prim_tests_per_wave_ray": round(64 * stats["wave_leaf_steps"] / stats["segments"], 2)}
+        # HBM bytes of k_trace per launch: FETCH_SIZE / WRITE_SIZE cannot be read from inside this process, so
+        # the per-path figure of the committed rocprofv3 --pmc passes over this workload is scaled to this run.
+        pmc = os.path.join(ROOT, "profiles", f"r01_{args.workload}_pmc_traffic.json")
+        if os.path.exists(pmc) and not (args.width or args.height):
+            with open(pmc) as f:
+                per_path = json.load(f)["kernels"]["k_trace"]["hbm_bytes_per_path"]
+            roofline["traffic"] = round(per_path * npix * spp * args.steps / trace_launches)
+            roofline["algorithmic_bytes_per_launch"] = round(bytes_per_step * args.steps / trace_launches)
+            roofline["traffic_source"] = os.path.relpath(pmc, ROOT)
     if world > 1:
         dist.barrier()
 
