@@ -236,6 +236,12 @@ int v4r_accum_clear(v4r_renderer *r);
  * PyRenderer::py_render (src/renderer.rs:450-476). */
 int v4r_accum_read(v4r_renderer *r, float *host_hwc, uint32_t *n_passes);
 
+/* Replace the accumulator's contents and pass count with host data (H*W*3 fp32 sums, row 0 = top):
+ * the restore half of a checkpoint, after which v4r_render(..., first_pass = n_passes, ...)
+ * continues the job.  RenderResult is a plain (Vec<f32>, count) pair (src/renderer.rs:336-340), so
+ * the reference's equivalent is constructing one from saved sums. */
+int v4r_accum_write(v4r_renderer *r, const float *host_hwc, uint32_t n_passes);
+
 /* Device address and length (floats) of the accumulator currently bound, for an RCCL reduce
  * issued by the caller after v4r_synchronize. */
 int v4r_accum_device(v4r_renderer *r, float **device_hwc, uint64_t *n_floats);

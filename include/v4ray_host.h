@@ -114,6 +114,16 @@ int v4rh_tonemap_u8(const float *sums, uint64_t n_floats, uint32_t n_passes, uin
 /* Write a 24-bit BMP or binary PPM (by extension) of an RGB image whose row 0 is the top. */
 int v4rh_write_image(const char *path, const uint8_t *rgb, uint32_t width, uint32_t height);
 
+/* Accumulator checkpoint: a restartable image of RenderResult (src/renderer.rs:336-340: the fp32
+ * sums and the pass count) plus what identifies the job (size, seed).  File = 48-byte header
+ * {"V4RCKPT1", width, height, n_passes, reserved, seed, FNV-1a-64 of the payload, payload bytes}
+ * followed by H*W*3 little-endian floats; written to "<path>.tmp" and renamed, so a crash while
+ * saving leaves the previous checkpoint intact.  Load rejects a truncated or corrupted file; sums
+ * may be NULL to read only the header. */
+int v4rh_checkpoint_save(const char *path, const float *sums, uint32_t width, uint32_t height, uint32_t n_passes, uint64_t seed);
+int v4rh_checkpoint_load(const char *path, uint32_t *width, uint32_t *height, uint32_t *n_passes, uint64_t *seed, float *sums,
+                         uint64_t capacity_floats);
+
 const char *v4rh_last_error(void);
 
 #ifdef __cplusplus

@@ -1032,6 +1032,15 @@ int v4r_accum_read(v4r_renderer *r, float *host_hwc, uint32_t *n_passes) {
     return V4R_OK;
 }
 
+int v4r_accum_write(v4r_renderer *r, const float *host_hwc, uint32_t n_passes) {
+    if (!r || !host_hwc) return set_error(V4R_E_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    HIP_TRY(hipMemcpy(r->accum, host_hwc, (size_t)r->npix * 3 * sizeof(float), hipMemcpyHostToDevice));
+    r->n_passes = n_passes;
+    return V4R_OK;
+}
+
 int v4r_accum_device(v4r_renderer *r, float **device_hwc, uint64_t *n_floats) {
     if (!r) return set_error(V4R_E_INVALID, "NULL renderer");
     if (device_hwc) *device_hwc = r->accum;

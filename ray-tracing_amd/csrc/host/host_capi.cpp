@@ -419,4 +419,69 @@ int v4rh_write_image(const char *path, const uint8_t *rgb, uint32_t width, uint3
     });
 }
 
+namespace {
+struct CheckpointHeader {
+    char magic[8];
+    uint32_t width, height, n_passes, reserved;
+    uint64_t seed, checksum, payload_bytes;
+};
+static_assert(sizeof(CheckpointHeader) == 48, "checkpoint header layout");
+uint64_t fnv1a64(const void *data, size_t n) {
+    const uint8_t *p = (const uint8_t *)data;
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (size_t i = 0; i < n; ++i) h = (h ^ p[i]) * 0x100000001b3ull;
+    return h;
+}
+}  // namespace
+
+int v4rh_checkpoint_save(const char *path, const float *sums, uint32_t width, uint32_t height, uint32_t n_passes, uint64_t seed) {
+    return guarded([&] {
+        if (!path || !sums) throw std::runtime_error("v4rh_checkpoint_save: NULL argument");
+        CheckpointHeader h;
+        std::memcpy(h.magic, "V4RCKPT1", 8);
+        h.width = width;
+        h.height = height;
+        h.n_passes = n_passes;
+        h.reserved = 0;
+        h.seed = seed;
+        h.payload_bytes = (uint64_t)width * height * 3 * sizeof(float);
+        h.checksum = fnv1a64(sums, (size_t)h.payload_bytes);
+        std::string p(path), tmp = p + ".tmp";
+        {
+            std::ofstream f(tmp, std::ios::binary | std::ios::trunc);
+            if (!f) throw std::runtime_error("cannot open checkpoint for writing: " + tmp);
+            f.write((const char *)&h, sizeof h);
+            f.write((const char *)sums, (std::streamsize)h.payload_bytes);
+            f.flush();
+            if (!f) throw std::runtime_error("failed writing checkpoint: " + tmp);
+        }
+        if (std::rename(tmp.c_str(), p.c_str()) != 0) throw std::runtime_error("cannot move checkpoint into place: " + p);
+        return 0;
+    });
+}
+
+int v4rh_checkpoint_load(const char *path, uint32_t *width, uint32_t *height, uint32_t *n_passes, uint64_t *seed, float *sums,
+                         uint64_t capacity_floats) {
+    return guarded([&] {
+        if (!path) throw std::runtime_error("v4rh_checkpoint_load: NULL path");
+        std::string p(path);
+        std::ifstream f(p, std::ios::binary);
+        if (!f) throw std::runtime_error("cannot open checkpoint: " + p);
+        CheckpointHeader h;
+        f.read((char *)&h, sizeof h);
+        if (!f || std::memcmp(h.magic, "V4RCKPT1", 8) != 0) throw std::runtime_error("not a checkpoint file: " + p);
+        if (h.payload_bytes != (uint64_t)h.width * h.height * 3 * sizeof(float)) throw std::runtime_error("checkpoint header is inconsistent: " + p);
+        if (width) *width = h.width;
+        if (height) *height = h.height;
+        if (n_passes) *n_passes = h.n_passes;
+        if (seed) *seed = h.seed;
+        if (!sums) return 0;
+        if (capacity_floats < h.payload_bytes / sizeof(float)) throw std::runtime_error("checkpoint does not fit the buffer: " + p);
+        f.read((char *)sums, (std::streamsize)h.payload_bytes);
+        if (!f || (uint64_t)f.gcount() != h.payload_bytes) throw std::runtime_error("checkpoint is truncated: " + p);
+        if (fnv1a64(sums, (size_t)h.payload_bytes) != h.checksum) throw std::runtime_error("checkpoint checksum mismatch: " + p);
+        return 0;
+    });
+}
+
 }  // extern "C"

@@ -3,6 +3,8 @@
 // Like the reference (src/main.rs:46-79) it renders 1-spp passes progressively, prints
 // "Iter N +Ts" as they complete and rewrites the output image every 5 seconds; unlike it, it
 // stops after --spp passes (the reference runs until Enter is pressed; --spp 0 does the same).
+// --checkpoint FILE makes a long job restartable: the accumulator and pass count are written there
+// with every image save, and an existing file of the same size and seed is resumed from.
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -18,7 +20,7 @@
 
 namespace {
 struct Opts {
-    std::string input = "scene.json", output = "output.bmp";
+    std::string input = "scene.json", output = "output.bmp", checkpoint;
     uint32_t spp = 64, batch = 8;
     uint64_t seed = 0x5EED, perlin_seed = 1;
     int device = 0;
@@ -43,6 +45,7 @@ bool parse(int argc, char **argv, Opts &o) {
         else if (a == "--perlin-seed") o.perlin_seed = std::strtoull(need("--perlin-seed"), nullptr, 0);
         else if (a == "--device") o.device = std::atoi(need("--device"));
         else if (a == "--pretransform-triangles") o.pretransform = true;
+        else if (a == "--checkpoint") o.checkpoint = need("--checkpoint");
         else if (a == "-h" || a == "--help") return false;
         else {
             fprintf(stderr, "unknown argument %s\n", a.c_str());
@@ -66,6 +69,49 @@ int save(v4r_renderer *r, uint32_t n, uint32_t w, uint32_t h, const std::string 
     printf("Iter %u saved\n", n);  // src/main.rs:74
     return 0;
 }
+
+int save_checkpoint(v4r_renderer *r, uint32_t w, uint32_t h, uint64_t seed, const std::string &path) {
+    std::vector<float> sums((size_t)w * h * 3);
+    uint32_t n = 0;
+    if (v4r_accum_read(r, sums.data(), &n) != V4R_OK) {
+        fprintf(stderr, "checkpoint: %s\n", v4r_last_error());
+        return 1;
+    }
+    if (v4rh_checkpoint_save(path.c_str(), sums.data(), w, h, n, seed) != 0) {
+        fprintf(stderr, "%s\n", v4rh_last_error());
+        return 1;
+    }
+    return 0;
+}
+
+// Resume from `path` if it holds a checkpoint of this job; returns the passes already done.
+int load_checkpoint(v4r_renderer *r, uint32_t w, uint32_t h, uint64_t seed, const std::string &path, uint32_t &done) {
+    FILE *probe = fopen(path.c_str(), "rb");
+    if (!probe) return 0;  // nothing to resume
+    fclose(probe);
+    uint32_t cw = 0, ch = 0, n = 0;
+    uint64_t cseed = 0;
+    if (v4rh_checkpoint_load(path.c_str(), &cw, &ch, &n, &cseed, nullptr, 0) != 0) {
+        fprintf(stderr, "%s\n", v4rh_last_error());
+        return 1;
+    }
+    if (cw != w || ch != h || cseed != seed) {
+        fprintf(stderr, "checkpoint %s is of another job (%ux%u seed %llu)\n", path.c_str(), cw, ch, (unsigned long long)cseed);
+        return 1;
+    }
+    std::vector<float> sums((size_t)w * h * 3);
+    if (v4rh_checkpoint_load(path.c_str(), nullptr, nullptr, nullptr, nullptr, sums.data(), sums.size()) != 0) {
+        fprintf(stderr, "%s\n", v4rh_last_error());
+        return 1;
+    }
+    if (v4r_accum_write(r, sums.data(), n) != V4R_OK) {
+        fprintf(stderr, "checkpoint: %s\n", v4r_last_error());
+        return 1;
+    }
+    done = n;
+    printf("Resumed at iter %u from %s\n", n, path.c_str());
+    return 0;
+}
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -73,7 +119,7 @@ int main(int argc, char **argv) {
     if (!parse(argc, argv, o)) {
         fprintf(stderr,
                 "usage: v4ray-hip [-i scene.json] [-o output.bmp] [--spp N (0 = until Enter)] [--batch N] [--seed S]\n"
-                "                 [--perlin-seed S] [--device D] [--pretransform-triangles]\n");
+                "                 [--perlin-seed S] [--device D] [--pretransform-triangles] [--checkpoint FILE]\n");
         return 2;
     }
     v4rh_scene *scene = nullptr;
@@ -106,6 +152,7 @@ int main(int argc, char **argv) {
     auto last_save = start;
     uint32_t done = 0;
     int rc = 0;
+    if (!o.checkpoint.empty() && load_checkpoint(r, desc->width, desc->height, o.seed, o.checkpoint, done) != 0) return 1;
     while (!quit && (o.spp == 0 || done < o.spp)) {
         uint32_t n = o.spp == 0 ? o.batch : std::min(o.batch, o.spp - done);
         if (v4r_render(r, o.seed, done, 1, n) != V4R_OK || v4r_synchronize(r) != V4R_OK) {
@@ -118,10 +165,12 @@ int main(int argc, char **argv) {
         printf("Iter %u +%llds\n", done, (long long)std::chrono::duration_cast<std::chrono::seconds>(now - start).count());  // src/main.rs:48-52
         if (now - last_save >= std::chrono::seconds(5)) {  // src/main.rs:68
             rc |= save(r, done, desc->width, desc->height, o.output);
+            if (!o.checkpoint.empty()) rc |= save_checkpoint(r, desc->width, desc->height, o.seed, o.checkpoint);
             last_save = now;
         }
     }
     if (rc == 0 && done > 0) rc = save(r, done, desc->width, desc->height, o.output);
+    if (rc == 0 && done > 0 && !o.checkpoint.empty()) rc = save_checkpoint(r, desc->width, desc->height, o.seed, o.checkpoint);
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
     if (done > 0)
         printf("%u passes of %ux%u in %.3f s = %.2f Mpaths/s\n", done, desc->width, desc->height, secs,

@@ -540,6 +540,28 @@ class Renderer:
         check_dev(device_lib().v4r_accum_read(self._h, out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(n)))
         return out, int(n.value)
 
+    def write_accumulator(self, sums: np.ndarray, n_passes: int) -> None:
+        """Restore the accumulator (H,W,3 fp32 sums) and its pass count, e.g. from a checkpoint."""
+        a = np.ascontiguousarray(sums, dtype=np.float32)
+        if a.shape != (self.height, self.width, 3):
+            raise ValueError(f"accumulator must be ({self.height}, {self.width}, 3)")
+        check_dev(device_lib().v4r_accum_write(self._h, a.ctypes.data_as(C.POINTER(C.c_float)), n_passes))
+
+    def save_checkpoint(self, path) -> int:
+        """Write the accumulator, pass count, size and seed to `path`; returns the pass count."""
+        sums, n = self.read_accumulator()
+        save_checkpoint(path, sums, n, self.seed)
+        return n
+
+    def load_checkpoint(self, path) -> int:
+        """Resume from a checkpoint of the same image size and seed; returns the passes it holds, so that
+        render_passes(k, first_pass=returned) continues the job."""
+        sums, n, seed = load_checkpoint(path)
+        if sums.shape != (self.height, self.width, 3) or seed != self.seed:
+            raise V4RayError(f"{path}: checkpoint of another job ({sums.shape[1]}x{sums.shape[0]}, seed {seed:#x})")
+        self.write_accumulator(sums, n)
+        return n
+
     def bind_accumulator(self, device_ptr: Optional[int]) -> None:
         check_dev(device_lib().v4r_accum_bind(self._h, C.c_void_p(device_ptr) if device_ptr else None))
 
@@ -635,6 +657,22 @@ def load_image(path) -> np.ndarray:
     check_host(lib.v4rh_image_load(os.fspath(path).encode(), C.byref(w), C.byref(h),
                                    out.ctypes.data_as(C.POINTER(C.c_uint8)), out.size))
     return out
+
+
+def save_checkpoint(path, sums: np.ndarray, n_passes: int, seed: int) -> None:
+    a = np.ascontiguousarray(sums, dtype=np.float32)
+    check_host(host_lib().v4rh_checkpoint_save(os.fspath(path).encode(), a.ctypes.data_as(C.POINTER(C.c_float)),
+                                               a.shape[1], a.shape[0], n_passes, seed))
+
+
+def load_checkpoint(path):
+    """-> (sums (H,W,3) float32, n_passes, seed); raises on a truncated or corrupted file."""
+    w, h, n, seed = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64()
+    p = os.fspath(path).encode()
+    check_host(host_lib().v4rh_checkpoint_load(p, C.byref(w), C.byref(h), C.byref(n), C.byref(seed), None, 0))
+    sums = np.empty((h.value, w.value, 3), dtype=np.float32)
+    check_host(host_lib().v4rh_checkpoint_load(p, None, None, None, None, sums.ctypes.data_as(C.POINTER(C.c_float)), sums.size))
+    return sums, int(n.value), int(seed.value)
 
 
 def write_image(path, rgb: np.ndarray) -> None:

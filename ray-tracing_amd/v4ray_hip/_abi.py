@@ -172,13 +172,15 @@ def host_lib():
     _sig(lib.v4rh_image_load, i32, cp, C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_uint8), u64)
     _sig(lib.v4rh_tonemap_u8, i32, fp, u64, u32, C.POINTER(C.c_uint8))
     _sig(lib.v4rh_write_image, i32, cp, C.POINTER(C.c_uint8), u32, u32)
+    _sig(lib.v4rh_checkpoint_save, i32, cp, fp, u32, u32, u32, u64)
+    _sig(lib.v4rh_checkpoint_load, i32, cp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u64), fp, u64)
     _host = lib
     return lib
 
 
 DEVICE_SYMBOLS = [
     "v4r_abi_version", "v4r_last_error", "v4r_renderer_create", "v4r_renderer_destroy", "v4r_render",
-    "v4r_accum_bind", "v4r_accum_clear", "v4r_accum_read", "v4r_accum_device", "v4r_tonemap_u8",
+    "v4r_accum_bind", "v4r_accum_clear", "v4r_accum_read", "v4r_accum_write", "v4r_accum_device", "v4r_tonemap_u8",
     "v4r_trace_primary", "v4r_trace_rays", "v4r_stats_enable", "v4r_stats_read", "v4r_synchronize",
     "v4r_stream", "v4r_pass_count", "v4r_profile_enable", "v4r_profile_read",
 ]
@@ -206,6 +208,7 @@ def device_lib():
     _sig(lib.v4r_accum_bind, i32, vp, vp)
     _sig(lib.v4r_accum_clear, i32, vp)
     _sig(lib.v4r_accum_read, i32, vp, fp, up)
+    _sig(lib.v4r_accum_write, i32, vp, fp, u32)
     _sig(lib.v4r_accum_device, i32, vp, C.POINTER(vp), C.POINTER(u64))
     _sig(lib.v4r_tonemap_u8, i32, vp, u32, C.POINTER(C.c_uint8))
     _sig(lib.v4r_trace_primary, i32, vp, up, fp)

@@ -198,6 +198,28 @@ def test_ray_order_covers_every_pixel_and_pass(size, spp):
     r.close()
 
 
+def test_checkpoint_resume_is_bit_identical(tmp_path):
+    """4 passes, checkpoint, a NEW renderer resumed from the file, 4 more passes == 8 passes in one go."""
+    scene, r = make("c3")
+    r.render_passes(8)
+    whole, _ = r.read_accumulator()
+    r.clear()
+    r.render_passes(4)
+    assert r.save_checkpoint(tmp_path / "c3.ckpt") == 4
+    r.close()
+    r2 = Renderer(scene.renderer_param, scene.camera_param, scene)
+    done = r2.load_checkpoint(tmp_path / "c3.ckpt")
+    assert done == 4
+    r2.render_passes(4, first_pass=done)
+    resumed, n = r2.read_accumulator()
+    assert n == 8 and np.array_equal(resumed, whole)
+    other = Renderer(scene.renderer_param, scene.camera_param, scene, seed=1234)
+    with pytest.raises(Exception, match="another job"):
+        other.load_checkpoint(tmp_path / "c3.ckpt")
+    other.close()
+    r2.close()
+
+
 def test_sample_split_over_ranks_matches_single_rank():
     """Rank r of N renders passes r, r+N, ...: the per-rank sums add up to the single-rank image
     (to fp32 reassociation) because pass p draws the same random streams wherever it runs."""

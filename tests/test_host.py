@@ -339,3 +339,34 @@ def test_scene_generators_are_deterministic():
     assert d.camera.lens_radius == pytest.approx(0.05)
     c4 = scenes.load("c4", 64, 36, subdivide=1)
     assert c4.flatten(c4.renderer_param, c4.camera_param).contents.n_prims == 4968 * 4 + 7
+
+
+def test_checkpoint_round_trip_and_corruption(tmp_path):
+    """Accumulator checkpoint (sums + pass count + size + seed): exact round trip, previous file survives as
+    the only file after a save, truncated / corrupted / foreign files are rejected with a message."""
+    from v4ray_hip import V4RayError, load_checkpoint, save_checkpoint
+    rng = np.random.default_rng(3)
+    sums = rng.random((7, 5, 3), dtype=np.float32) * 100
+    sums[0, 0, 0] = np.float32(np.inf)   # an overflowed pixel must survive too
+    path = tmp_path / "job.ckpt"
+    save_checkpoint(path, sums, 123, 0x5EED)
+    got, n, seed = load_checkpoint(path)
+    assert n == 123 and seed == 0x5EED and got.shape == (7, 5, 3) and np.array_equal(got, sums)
+    assert not (tmp_path / "job.ckpt.tmp").exists()
+    save_checkpoint(path, sums * 2, 246, 0x5EED)            # overwrite in place
+    assert load_checkpoint(path)[1] == 246
+    raw = path.read_bytes()
+    assert len(raw) == 48 + 7 * 5 * 3 * 4 and raw[:8] == b"V4RCKPT1"
+    (tmp_path / "cut.ckpt").write_bytes(raw[:-10])
+    with pytest.raises(V4RayError, match="truncated"):
+        load_checkpoint(tmp_path / "cut.ckpt")
+    flipped = bytearray(raw)
+    flipped[60] ^= 1
+    (tmp_path / "bad.ckpt").write_bytes(bytes(flipped))
+    with pytest.raises(V4RayError, match="checksum"):
+        load_checkpoint(tmp_path / "bad.ckpt")
+    (tmp_path / "other.ckpt").write_bytes(b"P6\n1 1\n255\n" + bytes(60))
+    with pytest.raises(V4RayError, match="not a checkpoint"):
+        load_checkpoint(tmp_path / "other.ckpt")
+    with pytest.raises(V4RayError, match="cannot open"):
+        load_checkpoint(tmp_path / "missing.ckpt")
