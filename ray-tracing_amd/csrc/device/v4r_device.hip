@@ -752,7 +752,20 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     HIP_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
 
     SceneDev &S = r->S;
-    if (int rc = r->upload(&S.nodes, (const float4 *)d->nodes, (size_t)d->n_nodes * 4)) return rc;
+    {  // interleave the two child boxes plane by plane (see trav_step)
+        std::vector<float4> dev((size_t)d->n_nodes * 4);
+        for (size_t i = 0; i < d->n_nodes; ++i) {
+            const v4r_bvh_node &n = d->nodes[i];
+            dev[4 * i + 0] = make_float4(n.lo0[0], n.lo1[0], n.lo0[1], n.lo1[1]);
+            dev[4 * i + 1] = make_float4(n.lo0[2], n.lo1[2], n.hi0[0], n.hi1[0]);
+            dev[4 * i + 2] = make_float4(n.hi0[1], n.hi1[1], n.hi0[2], n.hi1[2]);
+            float c0, c1;
+            std::memcpy(&c0, &n.child0, 4);
+            std::memcpy(&c1, &n.child1, 4);
+            dev[4 * i + 3] = make_float4(c0, c1, 0.0f, 0.0f);
+        }
+        if (int rc = r->upload(&S.nodes, dev.data(), dev.size())) return rc;
+    }
     if (int rc = r->upload(&S.prims, (const float4 *)d->prims, (size_t)d->n_prims * 3)) return rc;
     std::vector<uint32_t> info(d->n_prims);
     for (uint32_t i = 0; i < d->n_prims; ++i) {

@@ -22,7 +22,7 @@ enum {
 constexpr uint32_t NO_PRIM = 0xFFFFFFFFu;
 
 struct SceneDev {
-    const float4 *nodes;         // 4 x float4 per node (v4r_bvh_node)
+    const float4 *nodes;         // 4 x float4 per node: {lo0.x,lo1.x,lo0.y,lo1.y} {lo0.z,lo1.z,hi0.x,hi1.x} {hi0.y,hi1.y,hi0.z,hi1.z} {child0,child1,-,-}
     const float4 *prims;         // 3 x float4 per primitive (v4r_prim)
     const uint32_t *prim_info;   // material index | shading class << 24
     const float *xforms;         // 24 floats per transform (v4r_xform)
@@ -318,13 +318,23 @@ V4R_DEV uint32_t pop_cull(Stack &st, float best_t) {
 // interior children ordered near-first.
 template <bool COUNT>
 V4R_DEV void trav_step(const SceneDev &S, V3 o, V3 inv, Stack &st, const Best &best, Trav &T, TraceCounters &cnt) {
+    // Device node layout (DevNode): the planes of the two child boxes interleaved, so that one packed
+    // instruction (v_pk_add_f32 / v_pk_mul_f32) handles a plane of both children: the same roundings as
+    // slab(), half the instructions for the 24 subtractions and multiplications.
     const float4 *np = S.nodes + 4 * (size_t)T.node;
     float4 n0 = np[0], n1 = np[1], n2 = np[2];
     float2 kids = *reinterpret_cast<const float2 *>(np + 3);
     if (COUNT) cnt.nodes++;
-    float e0, e1;
-    bool h0 = slab(v3(n0.x, n0.y, n0.z), v3(n0.w, n1.x, n1.y), o, inv, e0) && e0 <= best.t;
-    bool h1 = slab(v3(n1.z, n1.w, n2.x), v3(n2.y, n2.z, n2.w), o, inv, e1) && e1 <= best.t;
+    typedef float pair __attribute__((ext_vector_type(2)));  // [child 0, child 1]
+    pair ax0 = (pair{n0.x, n0.y} - o.x) * inv.x, ax1 = (pair{n1.z, n1.w} - o.x) * inv.x;
+    pair ay0 = (pair{n0.z, n0.w} - o.y) * inv.y, ay1 = (pair{n2.x, n2.y} - o.y) * inv.y;
+    pair az0 = (pair{n1.x, n1.y} - o.z) * inv.z, az1 = (pair{n2.z, n2.w} - o.z) * inv.z;
+    float e0 = fmaxf(fmaxf(fminf(ax0.x, ax1.x), fminf(ay0.x, ay1.x)), fmaxf(fminf(az0.x, az1.x), EPSILON));
+    float f0 = fminf(fminf(fmaxf(ax0.x, ax1.x), fmaxf(ay0.x, ay1.x)), fmaxf(az0.x, az1.x));
+    float e1 = fmaxf(fmaxf(fminf(ax0.y, ax1.y), fminf(ay0.y, ay1.y)), fmaxf(fminf(az0.y, az1.y), EPSILON));
+    float f1 = fminf(fminf(fmaxf(ax0.y, ax1.y), fmaxf(ay0.y, ay1.y)), fmaxf(az0.y, az1.y));
+    bool h0 = e0 < f0 && e0 <= best.t;
+    bool h1 = e1 < f1 && e1 <= best.t;
     uint32_t c0 = __float_as_uint(kids.x), c1 = __float_as_uint(kids.y);
     bool l0 = h0 && (c0 & V4R_LEAF_BIT), l1 = h1 && (c1 & V4R_LEAF_BIT);
     bool i0 = h0 && !l0, i1 = h1 && !l1;
