@@ -115,10 +115,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # V4R_BENCH_REHEARSE=1: every rank on GPU 0 with the gloo backend, to rehearse the N > 1 code path on a
+    # one-GPU box (RCCL refuses two ranks on one device); the numbers of such a run mean nothing.
+    rehearse = os.environ.get("V4R_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     fw, fh, fspp = scenes.FULL_SIZE[args.workload]
     width, height = args.width or fw, args.height or fh
