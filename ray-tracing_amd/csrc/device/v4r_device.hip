@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "v4r_scene_dev.hpp"
@@ -554,6 +555,7 @@ struct Pipe {
     Queues Q{};
     hipEvent_t done = nullptr;  // recorded after the pipeline's latest k_resolve
     bool used = false;
+    std::vector<void *> allocations;  // the queues of Q, sized for Q.cap path slots
 };
 
 struct v4r_renderer {
@@ -580,6 +582,7 @@ struct v4r_renderer {
     bool has_class[CLS_COUNT] = {false, false, false, false, false, false};
     bool has_media = false;  // selects the kernels that carry the constant-medium test
     size_t ctr_bytes = 0;
+    uint32_t max_depth = 0, spill_depth = 0;
 
     template <class T>
     int alloc(T **out, size_t count) {
@@ -744,6 +747,44 @@ uint32_t grid_for(K kernel, int n_cu) {
     return (uint32_t)(n_cu * per_cu);
 }
 
+// Give `pipe` queues for at least `need` path slots.  Growing frees the old queues first (after the
+// pipeline has drained), so a renderer's footprint follows the largest batch it has been asked for:
+// ~384 B per slot with four material classes, i.e. 0.25 GB for one 800x800 pass and 12.7 GB for a 32 M batch.
+int ensure_pipe(v4r_renderer *r, Pipe &pipe, size_t need) {
+    Queues &Q = pipe.Q;
+    if (Q.cap >= need && !pipe.allocations.empty()) return V4R_OK;
+    HIP_TRY(hipStreamSynchronize(pipe.stream));
+    for (void *p : pipe.allocations) (void)hipFree(p);
+    pipe.allocations.clear();
+    Q = Queues{};
+    auto alloc = [&](auto **out, size_t count) -> int {
+        void *p = nullptr;
+        size_t bytes = std::max<size_t>(count * sizeof(**out), 256);
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess)
+            return set_error(V4R_E_HIP, std::string("hipMalloc of a ") + std::to_string(bytes >> 20) + " MiB queue: " + hipGetErrorString(e) +
+                                            " (V4R_BATCH_PATHS / V4R_PIPES reduce the footprint)");
+        pipe.allocations.push_back(p);
+        *out = (std::remove_reference_t<decltype(**out)> *)p;
+        return V4R_OK;
+    };
+    for (int p = 0; p < 2; ++p)
+        for (int c = 0; c < 3; ++c)
+            if (int rc = alloc(&Q.ray[p][c], need)) return rc;
+    for (int k = 0; k < CLS_COUNT; ++k)
+        for (int c = 0; c < 4; ++c)
+            if (int rc = alloc(&Q.hit[k][c], r->has_class[k] ? need : 1)) return rc;
+    if (int rc = alloc(&Q.hitd, need)) return rc;
+    if (int rc = alloc(&Q.rad, need)) return rc;
+    if (int rc = alloc(&Q.ctr, (size_t)r->max_depth + 1)) return rc;
+    HIP_TRY(hipMemset(Q.ctr, 0, r->ctr_bytes));
+    Q.stats = r->stats;
+    Q.spill_stride = (size_t)r->grid_trace * BLOCK;
+    if (int rc = alloc(&Q.spill, Q.spill_stride * std::max(r->spill_depth, 1u))) return rc;
+    Q.cap = (uint32_t)need;
+    return V4R_OK;
+}
+
 int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     HIP_TRY(hipSetDevice(r->device));
     hipDeviceProp_t prop;
@@ -839,27 +880,17 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     HIP_TRY(hipMemset(r->stats, 0, 64));
     HIP_TRY(hipEventCreateWithFlags(&r->fork, hipEventDisableTiming));
     r->pipes.resize(n_pipes);
+    r->max_depth = d->max_depth;
+    r->spill_depth = spill_depth;
     for (uint32_t pi = 0; pi < n_pipes; ++pi) {
         Pipe &pipe = r->pipes[pi];
         if (pi == 0) pipe.stream = r->stream;
         else HIP_TRY(hipStreamCreateWithFlags(&pipe.stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&pipe.done, hipEventDisableTiming));
-        Queues &Q = pipe.Q;
-        Q.cap = r->batch_passes * r->npix;
-        for (int p = 0; p < 2; ++p)
-            for (int c = 0; c < 3; ++c)
-                if (int rc = r->alloc(&Q.ray[p][c], Q.cap)) return rc;
-        for (int k = 0; k < CLS_COUNT; ++k)
-            for (int c = 0; c < 4; ++c)
-                if (int rc = r->alloc(&Q.hit[k][c], r->has_class[k] ? Q.cap : 1)) return rc;
-        if (int rc = r->alloc(&Q.hitd, Q.cap)) return rc;
-        if (int rc = r->alloc(&Q.rad, Q.cap)) return rc;
-        if (int rc = r->alloc(&Q.ctr, (size_t)d->max_depth + 1)) return rc;
-        HIP_TRY(hipMemset(Q.ctr, 0, r->ctr_bytes));
-        Q.stats = r->stats;
-        Q.spill_stride = r->grid_trace * BLOCK;
-        if (int rc = r->alloc(&Q.spill, (size_t)Q.spill_stride * std::max(spill_depth, 1u))) return rc;
     }
+    // Queues are sized by the jobs that arrive (ensure_pipe): pipeline 0 starts with room for one pass,
+    // which also gives v4r_trace_rays its stack spill slab.
+    if (int rc = ensure_pipe(r, r->pipes[0], r->npix)) return rc;
 
     if (int rc = r->alloc(&r->accum_own, (size_t)r->npix * 3)) return rc;
     HIP_TRY(hipMemset(r->accum_own, 0, (size_t)r->npix * 3 * sizeof(float)));
@@ -997,6 +1028,8 @@ void v4r_renderer_destroy(v4r_renderer *r) {
     for (auto &p : r->pipes)
         if (p.done) (void)hipEventDestroy(p.done);
     if (r->fork) (void)hipEventDestroy(r->fork);
+    for (auto &p : r->pipes)
+        for (void *q : p.allocations) (void)hipFree(q);
     for (void *p : r->allocations) (void)hipFree(p);
     for (hipEvent_t e : r->ev_pool) (void)hipEventDestroy(e);
     delete r;
@@ -1012,6 +1045,7 @@ int v4r_render(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_t pas
         uint32_t nb = std::min(r->batch_passes, n_passes - done);
         Pipe &pipe = r->pipes[r->next_pipe];
         r->next_pipe = (r->next_pipe + 1) % (uint32_t)r->pipes.size();
+        if (int rc = ensure_pipe(r, pipe, (size_t)nb * r->npix)) return rc;
         if (int rc = run_batch(r, pipe, seed, first_pass + done * pass_stride, pass_stride, nb)) return rc;
         done += nb;
     }
