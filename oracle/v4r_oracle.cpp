@@ -30,6 +30,7 @@
 //  * Recursion: ray_color's breadth-first recursion (renderer.rs:123-320) is run per path as a
 //    loop carrying the product of the per-bounce coefficients; colour = emitted + coef * child
 //    unrolls to the same sum of products.
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdint>
@@ -37,6 +38,7 @@
 #include <limits>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "v4ray_hip.h"
@@ -137,10 +139,12 @@ struct Counters {
     }
 };
 
+struct WideTree;
 struct Ctx {
     const v4r_scene_desc *s;
     uint32_t seg_key = 0;  // key of the segment being traced / shaded
     Counters cnt;
+    const WideTree *wide = nullptr;  // mode 1 only
 };
 
 // HitRecord::face_normal, hittable/mod.rs:146-154 (is_simd_negative on packed f32 is `< 0`)
@@ -373,48 +377,131 @@ void traverse_reference(Ctx &ctx, uint32_t node, const Ray &r, Closest &c) {
     }
 }
 
-// The device's traversal order (near child first, far child stacked with its entry distance,
-// subtrees skipped once their entry distance exceeds the closest hit), restated for the work
-// counters; it returns the same closest hit as traverse_reference.
-void traverse_ordered(Ctx &ctx, const Ray &r, Closest &c) {
+// The device's traversal, restated for the work counters (it returns the same closest hit as
+// traverse_reference): a 4-wide tree made from the binary one -- a wide node takes the two children
+// of a binary node and, while it has a free slot, replaces its interior child of largest surface
+// area (first on ties) by that child's two children -- walked near to far with one stack that holds
+// interior nodes and leaf primitives alike; an entry is skipped once its box entry distance exceeds
+// the closest hit.  Entry distances are carried with their two lowest mantissa bits replaced by the
+// child slot while the four children of a node are ordered, and cleared afterwards.
+struct WideNode {
+    float lo[4][3], hi[4][3];
+    uint32_t child[4];  // interior wide index, V4R_LEAF_BIT | primitive, or 0xFFFFFFFF for an empty slot
+};
+struct WideTree {
+    std::vector<WideNode> nodes;
+};
+
+WideTree build_wide(const v4r_scene_desc *s) {
+    WideTree w;
+    if (s->n_nodes == 0) return w;
+    struct Item {
+        float lo[3], hi[3];
+        uint32_t child;
+    };
+    auto split = [&](uint32_t node, Item &a, Item &b) {
+        const v4r_bvh_node &n = s->nodes[node];
+        for (int k = 0; k < 3; ++k) {
+            a.lo[k] = n.lo0[k];
+            a.hi[k] = n.hi0[k];
+            b.lo[k] = n.lo1[k];
+            b.hi[k] = n.hi1[k];
+        }
+        a.child = n.child0;
+        b.child = n.child1;
+    };
+    std::vector<std::pair<uint32_t, uint32_t>> todo{{0u, 0u}};  // (binary node, wide node)
+    w.nodes.resize(1);
+    while (!todo.empty()) {
+        auto [binary, wide] = todo.back();
+        todo.pop_back();
+        Item items[4];
+        int n = 2;
+        split(binary, items[0], items[1]);
+        while (n < 4) {
+            int pick = -1;
+            float best = -1.0f;
+            for (int k = 0; k < n; ++k) {
+                if (items[k].child & V4R_LEAF_BIT) continue;
+                float dx = items[k].hi[0] - items[k].lo[0], dy = items[k].hi[1] - items[k].lo[1], dz = items[k].hi[2] - items[k].lo[2];
+                float area = 2.0f * (dx * dy + dy * dz + dz * dx);
+                if (!(area == area)) area = INF;
+                if (pick < 0 || area > best) {
+                    pick = k;
+                    best = area;
+                }
+            }
+            if (pick < 0) break;
+            uint32_t node = items[pick].child;
+            split(node, items[pick], items[n]);
+            ++n;
+        }
+        WideNode out{};
+        for (int k = 0; k < 4; ++k) {
+            if (k >= n) {
+                out.child[k] = 0xFFFFFFFFu;
+                continue;
+            }
+            for (int a = 0; a < 3; ++a) {
+                out.lo[k][a] = items[k].lo[a];
+                out.hi[k][a] = items[k].hi[a];
+            }
+            if (items[k].child & V4R_LEAF_BIT) {
+                out.child[k] = items[k].child;
+            } else {
+                out.child[k] = (uint32_t)w.nodes.size();
+                w.nodes.emplace_back();
+                todo.push_back({items[k].child, out.child[k]});
+            }
+        }
+        w.nodes[wide] = out;
+    }
+    return w;
+}
+
+void traverse_wide(Ctx &ctx, const WideTree &tree, const Ray &r, Closest &c) {
     struct Entry {
-        uint32_t node;
+        uint32_t child;
         float entry;
     };
     std::vector<Entry> stack;
-    uint32_t node = 0;
+    auto bits = [](float f) {
+        uint32_t u;
+        std::memcpy(&u, &f, 4);
+        return u;
+    };
+    auto from_bits = [](uint32_t u) {
+        float f;
+        std::memcpy(&f, &u, 4);
+        return f;
+    };
+    Entry cur{0u, 0.0f};
     while (true) {
-        const v4r_bvh_node &n = ctx.s->nodes[node];
-        ctx.cnt.nodes++;
-        float e0 = 0, e1 = 0;
-        bool h0 = slab(n.lo0, n.hi0, r, EPSILON, INF, e0) && e0 <= c.hit.t;
-        bool h1 = slab(n.lo1, n.hi1, r, EPSILON, INF, e1) && e1 <= c.hit.t;
-        if (h0 && (n.child0 & V4R_LEAF_BIT)) {
-            consider(ctx, c, n.child0 & ~V4R_LEAF_BIT, r);
-            h0 = false;
-        }
-        if (h1 && (n.child1 & V4R_LEAF_BIT)) {
-            // the first leaf may have shortened the interval
-            if (e1 <= c.hit.t) consider(ctx, c, n.child1 & ~V4R_LEAF_BIT, r);
-            h1 = false;
-        }
-        if (h0 && h1) {
-            bool first0 = e0 <= e1;
-            stack.push_back(first0 ? Entry{n.child1, e1} : Entry{n.child0, e0});
-            node = first0 ? n.child0 : n.child1;
-            continue;
-        }
-        if (h0 || h1) {
-            node = h0 ? n.child0 : n.child1;
-            float e = h0 ? e0 : e1;
-            if (e <= c.hit.t) continue;
+        if (cur.child & V4R_LEAF_BIT) {
+            if (cur.entry <= c.hit.t) consider(ctx, c, cur.child & ~V4R_LEAF_BIT, r);
+        } else {
+            const WideNode &n = tree.nodes[cur.child];
+            ctx.cnt.nodes++;
+            uint32_t key[4];
+            for (int k = 0; k < 4; ++k) {
+                float e = 0.0f;
+                bool hit = n.child[k] != 0xFFFFFFFFu && slab(n.lo[k], n.hi[k], r, EPSILON, INF, e) && e <= c.hit.t;
+                key[k] = hit ? ((bits(e) & ~3u) | (uint32_t)k) : 0xFFFFFFFFu;
+            }
+            std::sort(key, key + 4);
+            for (int k = 3; k >= 1; --k)
+                if (key[k] != 0xFFFFFFFFu) stack.push_back({n.child[key[k] & 3u], from_bits(key[k] & ~3u)});
+            if (key[0] != 0xFFFFFFFFu) {
+                cur = {n.child[key[0] & 3u], from_bits(key[0] & ~3u)};
+                continue;
+            }
         }
         bool found = false;
         while (!stack.empty()) {
             Entry e = stack.back();
             stack.pop_back();
             if (e.entry <= c.hit.t) {
-                node = e.node;
+                cur = e;
                 found = true;
                 break;
             }
@@ -432,7 +519,7 @@ Closest trace(Ctx &ctx, const Ray &r, int mode) {
         consider(ctx, c, 0, r);
         return c;
     }
-    if (mode == 1) traverse_ordered(ctx, r, c);
+    if (mode == 1) traverse_wide(ctx, *ctx.wide, r, c);
     else traverse_reference(ctx, 0, r, c);
     return c;
 }
@@ -846,8 +933,11 @@ int v4o_render(const v4r_scene_desc *s, uint64_t seed, uint32_t first_pass, uint
     std::atomic<uint32_t> next{0};
     const uint32_t chunk = 256;
     std::vector<Counters> counters((size_t)n_threads);
+    WideTree wide;
+    if (mode == 1) wide = build_wide(s);
     auto worker = [&](int tid) {
         Ctx ctx{s};
+        ctx.wide = &wide;
         while (true) {
             uint32_t begin = next.fetch_add(chunk);
             if (begin >= npix) break;
@@ -885,6 +975,9 @@ int v4o_render(const v4r_scene_desc *s, uint64_t seed, uint32_t first_pass, uint
 int v4o_trace_primary(const v4r_scene_desc *s, uint32_t *prim_id, float *t, int mode) {
     if (int rc = validate(s)) return rc;
     Ctx ctx{s};
+    WideTree wide;
+    if (mode == 1) wide = build_wide(s);
+    ctx.wide = &wide;
     uint32_t npix = s->width * s->height;
     for (uint32_t pix = 0; pix < npix; ++pix) {
         Ray r = camera_ray(s, pix / s->width, pix % s->width, 0, true);
@@ -923,6 +1016,9 @@ int v4o_trace_rays(const v4r_scene_desc *s, uint32_t n, const float *origin, con
                    uint32_t *prim_id, float *t, float *rec, int mode) {
     if (int rc = validate(s)) return rc;
     Ctx ctx{s};
+    WideTree wide;
+    if (mode == 1) wide = build_wide(s);
+    ctx.wide = &wide;
     for (uint32_t i = 0; i < n; ++i) {
         Ray r{v3(origin + 3 * i), v3(dir + 3 * i)};
         ctx.seg_key = segment_key(path_key(seed, 0, i), 0);

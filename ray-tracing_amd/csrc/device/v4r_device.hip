@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -747,6 +748,92 @@ uint32_t grid_for(K kernel, int n_cu) {
     return (uint32_t)(n_cu * per_cu);
 }
 
+// The 4-wide tree of wide_step from the host's binary tree: a wide node starts with the two children
+// of a binary node and, while it has a free slot, replaces its interior child of largest surface area
+// by that child's two children.  Leaves stay single primitives, so the set of (ray, primitive) tests
+// that can happen is the one of the binary tree.  Nodes are emitted parent before children, siblings
+// next to each other.
+uint32_t collapse_to_wide(const v4r_scene_desc *d, std::vector<float4> &out) {
+    out.clear();
+    if (d->n_nodes == 0) return 0;
+    struct Item {
+        float lo[3], hi[3];
+        uint32_t child;  // word of the binary tree: interior index or V4R_LEAF_BIT | primitive
+    };
+    auto area = [](const Item &it) {
+        float dx = it.hi[0] - it.lo[0], dy = it.hi[1] - it.lo[1], dz = it.hi[2] - it.lo[2];
+        return 2.0f * (dx * dy + dy * dz + dz * dx);
+    };
+    auto children = [&](uint32_t node, Item &a, Item &b) {
+        const v4r_bvh_node &n = d->nodes[node];
+        std::memcpy(a.lo, n.lo0, 12);
+        std::memcpy(a.hi, n.hi0, 12);
+        a.child = n.child0;
+        std::memcpy(b.lo, n.lo1, 12);
+        std::memcpy(b.hi, n.hi1, 12);
+        b.child = n.child1;
+    };
+    struct Task {
+        uint32_t binary, wide, depth;
+    };
+    std::vector<Task> todo{{0u, 0u, 1u}};
+    uint32_t depth = 0;
+    out.resize(8);
+    const float inf = std::numeric_limits<float>::infinity();
+    while (!todo.empty()) {
+        Task t = todo.back();
+        todo.pop_back();
+        depth = std::max(depth, t.depth);
+        Item items[4];
+        int n = 2;
+        children(t.binary, items[0], items[1]);
+        while (n < 4) {
+            int pick = -1;
+            float best = -1.0f;
+            for (int k = 0; k < n; ++k)
+                if (!(items[k].child & V4R_LEAF_BIT)) {
+                    float a = area(items[k]);
+                    if (!(a == a)) a = inf;  // a box with a NaN extent is expanded first
+                    if (pick < 0 || a > best) {
+                        pick = k;
+                        best = a;
+                    }
+                }
+            if (pick < 0) break;
+            uint32_t node = items[pick].child;
+            children(node, items[pick], items[n]);
+            ++n;
+        }
+        float lo[3][4], hi[3][4];
+        uint32_t child[4];
+        for (int k = 0; k < 4; ++k) {
+            for (int a = 0; a < 3; ++a) {
+                // NaN planes make every comparison of the slab test false (an inverted box would not: the test
+                // orders the two planes of an axis itself)
+                lo[a][k] = k < n ? items[k].lo[a] : std::numeric_limits<float>::quiet_NaN();
+                hi[a][k] = k < n ? items[k].hi[a] : std::numeric_limits<float>::quiet_NaN();
+            }
+            if (k >= n) child[k] = 0xFFFFFFFFu;
+            else if (items[k].child & V4R_LEAF_BIT) child[k] = items[k].child;
+            else {
+                child[k] = (uint32_t)(out.size() / 8);
+                out.resize(out.size() + 8);
+                todo.push_back({items[k].child, child[k], t.depth + 1u});
+            }
+        }
+        float4 *w = out.data() + 8 * (size_t)t.wide;
+        for (int a = 0; a < 3; ++a) {
+            w[a] = make_float4(lo[a][0], lo[a][1], lo[a][2], lo[a][3]);
+            w[3 + a] = make_float4(hi[a][0], hi[a][1], hi[a][2], hi[a][3]);
+        }
+        float c[4];
+        std::memcpy(c, child, 16);
+        w[6] = make_float4(c[0], c[1], c[2], c[3]);
+        w[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    return depth;  // in wide nodes, root = 1
+}
+
 // Give `pipe` queues for at least `need` path slots.  Growing frees the old queues first (after the
 // pipeline has drained), so a renderer's footprint follows the largest batch it has been asked for:
 // ~384 B per slot with four material classes, i.e. 0.25 GB for one 800x800 pass and 12.7 GB for a 32 M batch.
@@ -786,6 +873,8 @@ int ensure_pipe(v4r_renderer *r, Pipe &pipe, size_t need) {
 }
 
 int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
+    (void)bvh_depth;  // the traversal stack is sized by the wide tree made below
+    uint32_t wide_depth = 0;
     HIP_TRY(hipSetDevice(r->device));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, r->device));
@@ -793,19 +882,10 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     HIP_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
 
     SceneDev &S = r->S;
-    {  // interleave the two child boxes plane by plane (see trav_step)
-        std::vector<float4> dev((size_t)d->n_nodes * 4);
-        for (size_t i = 0; i < d->n_nodes; ++i) {
-            const v4r_bvh_node &n = d->nodes[i];
-            dev[4 * i + 0] = make_float4(n.lo0[0], n.lo1[0], n.lo0[1], n.lo1[1]);
-            dev[4 * i + 1] = make_float4(n.lo0[2], n.lo1[2], n.hi0[0], n.hi1[0]);
-            dev[4 * i + 2] = make_float4(n.hi0[1], n.hi1[1], n.hi0[2], n.hi1[2]);
-            float c0, c1;
-            std::memcpy(&c0, &n.child0, 4);
-            std::memcpy(&c1, &n.child1, 4);
-            dev[4 * i + 3] = make_float4(c0, c1, 0.0f, 0.0f);
-        }
-        if (int rc = r->upload(&S.nodes, dev.data(), dev.size())) return rc;
+    {
+        std::vector<float4> wide;
+        wide_depth = collapse_to_wide(d, wide);
+        if (int rc = r->upload(&S.nodes4, wide.data(), wide.size())) return rc;
     }
     if (int rc = r->upload(&S.prims, (const float4 *)d->prims, (size_t)d->n_prims * 3)) return rc;
     std::vector<uint32_t> info(d->n_prims);
@@ -874,7 +954,9 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
                                  : std::max(grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, false>, n_cu), grid_for(k_trace_rays<false>, n_cu));
     r->grid_shade = (uint32_t)n_cu * 8u;
     r->grid_stream = (uint32_t)n_cu * 8u;
-    uint32_t spill_depth = bvh_depth > (uint32_t)LDS_DEPTH ? bvh_depth - LDS_DEPTH : 0;
+    // a ray's stack holds at most three entries per level of the wide tree above its current node
+    uint32_t stack_max = 3u * wide_depth + 1u;
+    uint32_t spill_depth = stack_max > (uint32_t)LDS_DEPTH ? stack_max - LDS_DEPTH : 0;
     r->ctr_bytes = sizeof(SegCtr) * ((size_t)d->max_depth + 1);
     if (int rc = r->alloc(&r->stats, 8)) return rc;
     HIP_TRY(hipMemset(r->stats, 0, 64));

@@ -22,7 +22,7 @@ enum {
 constexpr uint32_t NO_PRIM = 0xFFFFFFFFu;
 
 struct SceneDev {
-    const float4 *nodes;         // 4 x float4 per node: {lo0.x,lo1.x,lo0.y,lo1.y} {lo0.z,lo1.z,hi0.x,hi1.x} {hi0.y,hi1.y,hi0.z,hi1.z} {child0,child1,-,-}
+    const float4 *nodes4;        // 8 x float4 per 4-wide node (wide_step)
     const float4 *prims;         // 3 x float4 per primitive (v4r_prim)
     const uint32_t *prim_info;   // material index | shading class << 24
     const float *xforms;         // 24 floats per transform (v4r_xform)
@@ -62,21 +62,6 @@ struct Prim {
 V4R_DEV Prim load_prim(const float4 *prims, uint32_t i) {
     const float4 *p = prims + 3 * (size_t)i;
     return Prim{p[0], p[1], p[2]};
-}
-
-// ---- Ray::intersects_aabb, ray.rs:167-189 -------------------------------------------------------
-// Same running-interval test with strict tmin < tmax; the per-axis divisions become multiplications
-// by a reciprocal computed once per ray.
-V4R_DEV bool slab(V3 lo, V3 hi, V3 o, V3 inv, float &entry) {
-    float ax0 = (lo.x - o.x) * inv.x, ax1 = (hi.x - o.x) * inv.x;
-    float ay0 = (lo.y - o.y) * inv.y, ay1 = (hi.y - o.y) * inv.y;
-    float az0 = (lo.z - o.z) * inv.z, az1 = (hi.z - o.z) * inv.z;
-    // The running interval only ever shrinks, so testing tmin < tmax once after the third axis accepts
-    // exactly the boxes the per-axis tests accept; nested min/max map to v_min3_f32 / v_max3_f32.
-    float t_near = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fmaxf(fminf(az0, az1), EPSILON));
-    float t_far = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fmaxf(az0, az1));
-    entry = t_near;
-    return t_near < t_far;
 }
 
 // ---- primitive intersection (distance only) -----------------------------------------------------
@@ -272,115 +257,125 @@ struct Stack {
     }
 };
 
-// BVH::traverse (bvh/bvh.rs:182-239) + closest-hit selection (renderer.rs:149-183), restructured
-// for a wave of 64 rays.  Per ray: near child first, far child stacked with its entry distance,
-// subtrees skipped once their entry distance exceeds the closest hit; leaf children are tested right
-// after the node that holds them.  The closest hit is the same one the reference's candidate-set
-// traversal selects.  Across the wave the kinds of work run in separate phases, so that the
-// primitive-intersection code is not executed (mostly masked off) on every node step: a lane that
-// reaches a leaf parks it and idles while the other lanes keep stepping through interior nodes
-// (trav_step); once enough lanes are parked the parked leaves are intersected together
-// (trav_leaves).  The order of node visits and primitive tests of each ray is unchanged by the phasing.
 #ifndef V4R_VOTE_NUM
 #define V4R_VOTE_NUM 1
 #define V4R_VOTE_DEN 2
 #endif
 constexpr uint32_t TRAV_NONE = 0xFFFFFFFFu;
 
-struct Trav {
-    uint32_t node;         // interior node to visit next, TRAV_NONE when the ray is finished (or absent)
-    float node_entry;      // its box entry distance
-    uint32_t pend0, pend1; // parked leaf primitives of the last visited node (child 0's, child 1's)
-    float pend1_entry;
-    __device__ __forceinline__ bool parked() const { return (pend0 & pend1) != TRAV_NONE; }
-    __device__ __forceinline__ bool stepping() const { return node != TRAV_NONE && !parked(); }
+// ---- traversal -------------------------------------------------------------------------------------
+// BVH::traverse (bvh/bvh.rs:182-239) + closest-hit selection (renderer.rs:149-183), restructured for a
+// wave of 64 rays over a 4-wide tree (built from the host's binary tree when the scene is uploaded: a
+// node's children are its grandchildren where that fits): half as many dependent node fetches per
+// ray as the binary tree, each one 128-byte line.  The closest hit is the one the reference's
+// candidate-set traversal selects (ties go to the lowest primitive index, whatever the visiting order).
+// Across the wave the kinds of work run in separate phases chosen by vote, so that the
+// primitive-intersection code is not executed (mostly masked off) on every node step: a lane whose
+// current entry is a primitive idles while the others keep expanding interior nodes; once at least
+// V4R_VOTE_NUM/V4R_VOTE_DEN of the live lanes wait like that, their primitives are intersected together.  Every child that the ray enters -- interior node or leaf
+// primitive -- goes through one stack ordered near to far, so a lane's state is just the entry it
+// is working on: an interior node (expand it: wide_step) or a primitive (parked until the wave runs
+// the leaf phase: wide_leaves).  Stack entries carry the box entry distance with its two lowest
+// mantissa bits cleared (they hold the child slot while the four children are sorted); the value is
+// only ever compared as `entry <= closest hit`, for which a slightly smaller entry is merely
+// conservative.
+//
+// Node layout (8 float4): lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4] child[4] pad[4]; an
+// empty slot has NaN planes (never entered) and child word TRAV_NONE.
+struct Wide {
+    uint32_t cur;      // interior node index, V4R_LEAF_BIT | primitive, or TRAV_NONE when finished / absent
+    float cur_entry;
+    __device__ __forceinline__ bool parked() const { return cur != TRAV_NONE && (cur & V4R_LEAF_BIT); }
+    __device__ __forceinline__ bool stepping() const { return !(cur & V4R_LEAF_BIT); }
     __device__ __forceinline__ void start() {
-        node = 0u;
-        node_entry = 0.0f;  // the root has no box
-        pend0 = pend1 = TRAV_NONE;
-        pend1_entry = 0.0f;
+        cur = 0u;
+        cur_entry = 0.0f;
     }
     __device__ __forceinline__ void clear() {
-        node = pend0 = pend1 = TRAV_NONE;
-        node_entry = pend1_entry = 0.0f;
+        cur = TRAV_NONE;
+        cur_entry = 0.0f;
     }
 };
 
-V4R_DEV uint32_t pop_cull(Stack &st, float best_t) {
+V4R_DEV void wide_pop(Stack &st, float best_t, Wide &W) {
+    W.cur = TRAV_NONE;
     while (st.sp > 0) {
         uint2 e = st.pop();
-        if (__uint_as_float(e.y) <= best_t) return e.x;
-    }
-    return TRAV_NONE;
-}
-
-// One interior-node visit of a lane with T.stepping(): both child boxes, leaf children parked,
-// interior children ordered near-first.
-template <bool COUNT>
-V4R_DEV void trav_step(const SceneDev &S, V3 o, V3 inv, Stack &st, const Best &best, Trav &T, TraceCounters &cnt) {
-    // Device node layout (DevNode): the planes of the two child boxes interleaved, so that one packed
-    // instruction (v_pk_add_f32 / v_pk_mul_f32) handles a plane of both children: the same roundings as
-    // slab(), half the instructions for the 24 subtractions and multiplications.
-    const float4 *np = S.nodes + 4 * (size_t)T.node;
-    float4 n0 = np[0], n1 = np[1], n2 = np[2];
-    float2 kids = *reinterpret_cast<const float2 *>(np + 3);
-    if (COUNT) cnt.nodes++;
-    typedef float pair __attribute__((ext_vector_type(2)));  // [child 0, child 1]
-    pair ax0 = (pair{n0.x, n0.y} - o.x) * inv.x, ax1 = (pair{n1.z, n1.w} - o.x) * inv.x;
-    pair ay0 = (pair{n0.z, n0.w} - o.y) * inv.y, ay1 = (pair{n2.x, n2.y} - o.y) * inv.y;
-    pair az0 = (pair{n1.x, n1.y} - o.z) * inv.z, az1 = (pair{n2.z, n2.w} - o.z) * inv.z;
-    float e0 = fmaxf(fmaxf(fminf(ax0.x, ax1.x), fminf(ay0.x, ay1.x)), fmaxf(fminf(az0.x, az1.x), EPSILON));
-    float f0 = fminf(fminf(fmaxf(ax0.x, ax1.x), fmaxf(ay0.x, ay1.x)), fmaxf(az0.x, az1.x));
-    float e1 = fmaxf(fmaxf(fminf(ax0.y, ax1.y), fminf(ay0.y, ay1.y)), fmaxf(fminf(az0.y, az1.y), EPSILON));
-    float f1 = fminf(fminf(fmaxf(ax0.y, ax1.y), fmaxf(ay0.y, ay1.y)), fmaxf(az0.y, az1.y));
-    bool h0 = e0 < f0 && e0 <= best.t;
-    bool h1 = e1 < f1 && e1 <= best.t;
-    uint32_t c0 = __float_as_uint(kids.x), c1 = __float_as_uint(kids.y);
-    bool l0 = h0 && (c0 & V4R_LEAF_BIT), l1 = h1 && (c1 & V4R_LEAF_BIT);
-    bool i0 = h0 && !l0, i1 = h1 && !l1;
-    T.pend0 = l0 ? (c0 & ~V4R_LEAF_BIT) : TRAV_NONE;
-    T.pend1 = l1 ? (c1 & ~V4R_LEAF_BIT) : TRAV_NONE;
-    T.pend1_entry = e1;
-    if (i0 && i1) {
-        bool first0 = e0 <= e1;
-        st.push(first0 ? c1 : c0, first0 ? e1 : e0);
-        T.node = first0 ? c0 : c1;
-        T.node_entry = first0 ? e0 : e1;
-    } else if (i0 || i1) {
-        T.node = i0 ? c0 : c1;
-        T.node_entry = i0 ? e0 : e1;
-    } else {
-        T.node = TRAV_NONE;
-    }
-    if (!(l0 || l1) && T.node == TRAV_NONE) T.node = pop_cull(st, best.t);
-}
-
-// Intersect the parked leaves of every lane of the wave (child 0's before child 1's), then settle
-// which node each of those lanes visits next.  Called by the whole wave.
-template <bool COUNT, bool MEDIA, class KeyFn>
-V4R_DEV void trav_leaves(const SceneDev &S, V3 o, V3 d, Stack &st, Best &best, Trav &T, TraceCounters &cnt, KeyFn key) {
-    bool parked = T.parked();
-#pragma unroll 1
-    for (int k = 0; k < 2; ++k) {
-        uint32_t prim = k == 0 ? T.pend0 : T.pend1;
-        // the first test may have shortened the interval past the second leaf's box
-        bool go = prim != TRAV_NONE && (k == 0 || T.pend1_entry <= best.t);
-        if (__ballot(go) == 0ull) continue;
-        if (COUNT) cnt.wave_leaves++;
-        if (go) {
-            if (COUNT) cnt.prims++;
-            consider<MEDIA>(S, prim, o, d, best, key);
+        if (__uint_as_float(e.y) <= best_t) {
+            W.cur = e.x;
+            W.cur_entry = __uint_as_float(e.y);
+            return;
         }
     }
-    if (parked) {
-        if (T.node != TRAV_NONE && !(T.node_entry <= best.t)) T.node = TRAV_NONE;
-        if (T.node == TRAV_NONE) T.node = pop_cull(st, best.t);
-        T.pend0 = T.pend1 = TRAV_NONE;
+}
+
+template <bool COUNT>
+V4R_DEV void wide_step(const SceneDev &S, V3 o, V3 inv, Stack &st, const Best &best, Wide &W, TraceCounters &cnt) {
+    const float4 *np = S.nodes4 + 8 * (size_t)W.cur;
+    float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5];
+    float4 kids = np[6];
+    if (COUNT) cnt.nodes++;
+    // Ray::intersects_aabb (ray.rs:167-189): the same running-interval test with strict tmin < tmax, the
+    // per-axis divisions replaced by multiplications with a reciprocal computed once per ray; the interval
+    // only ever shrinks, so testing it once after the third axis accepts exactly the same boxes.  Two
+    // children per packed instruction (v_pk_add_f32 / v_pk_mul_f32), min/max as v_min3/v_max3.
+    typedef float pair __attribute__((ext_vector_type(2)));
+    uint32_t key[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {  // children (0,1) then (2,3), two per packed instruction
+        pair ax0 = ((h ? pair{lx.z, lx.w} : pair{lx.x, lx.y}) - o.x) * inv.x, ax1 = ((h ? pair{hx.z, hx.w} : pair{hx.x, hx.y}) - o.x) * inv.x;
+        pair ay0 = ((h ? pair{ly.z, ly.w} : pair{ly.x, ly.y}) - o.y) * inv.y, ay1 = ((h ? pair{hy.z, hy.w} : pair{hy.x, hy.y}) - o.y) * inv.y;
+        pair az0 = ((h ? pair{lz.z, lz.w} : pair{lz.x, lz.y}) - o.z) * inv.z, az1 = ((h ? pair{hz.z, hz.w} : pair{hz.x, hz.y}) - o.z) * inv.z;
+        float e0 = fmaxf(fmaxf(fminf(ax0.x, ax1.x), fminf(ay0.x, ay1.x)), fmaxf(fminf(az0.x, az1.x), EPSILON));
+        float f0 = fminf(fminf(fmaxf(ax0.x, ax1.x), fmaxf(ay0.x, ay1.x)), fmaxf(az0.x, az1.x));
+        float e1 = fmaxf(fmaxf(fminf(ax0.y, ax1.y), fminf(ay0.y, ay1.y)), fmaxf(fminf(az0.y, az1.y), EPSILON));
+        float f1 = fminf(fminf(fmaxf(ax0.y, ax1.y), fmaxf(ay0.y, ay1.y)), fmaxf(az0.y, az1.y));
+        // entry distances are >= EPSILON > 0, so their bit patterns order like the floats
+        key[2 * h] = (e0 < f0 && e0 <= best.t) ? ((__float_as_uint(e0) & ~3u) | (uint32_t)(2 * h)) : 0xFFFFFFFFu;
+        key[2 * h + 1] = (e1 < f1 && e1 <= best.t) ? ((__float_as_uint(e1) & ~3u) | (uint32_t)(2 * h + 1)) : 0xFFFFFFFFu;
+    }
+    // sort the four keys ascending (5 compare-exchanges); missed children sort last
+    auto cas = [&](int a, int b) {
+        uint32_t lo = min(key[a], key[b]), hi = max(key[a], key[b]);
+        key[a] = lo;
+        key[b] = hi;
+    };
+    cas(0, 1);
+    cas(2, 3);
+    cas(0, 2);
+    cas(1, 3);
+    cas(1, 2);
+    auto child_of = [&](uint32_t k) {
+        uint32_t slot = k & 3u;
+        float c = slot == 0u ? kids.x : (slot == 1u ? kids.y : (slot == 2u ? kids.z : kids.w));
+        return __float_as_uint(c);
+    };
+    // farther children first, so that the nearest of them is popped first
+    if (key[3] != 0xFFFFFFFFu) st.push(child_of(key[3]), __uint_as_float(key[3] & ~3u));
+    if (key[2] != 0xFFFFFFFFu) st.push(child_of(key[2]), __uint_as_float(key[2] & ~3u));
+    if (key[1] != 0xFFFFFFFFu) st.push(child_of(key[1]), __uint_as_float(key[1] & ~3u));
+    if (key[0] != 0xFFFFFFFFu) {
+        W.cur = child_of(key[0]);
+        W.cur_entry = __uint_as_float(key[0] & ~3u);
+    } else {
+        wide_pop(st, best.t, W);
     }
 }
 
-// Closest hit of one ray per lane.  Must be called by every lane of the wave; lanes with
-// active == false only take part in the votes.
+// Intersect the parked primitive of every lane of the wave, then pop what each of those lanes does next.
+template <bool COUNT, bool MEDIA, class KeyFn>
+V4R_DEV void wide_leaves(const SceneDev &S, V3 o, V3 d, Stack &st, Best &best, Wide &W, TraceCounters &cnt, KeyFn key) {
+    bool parked = W.parked();
+    if (COUNT) cnt.wave_leaves++;
+    if (parked) {
+        if (W.cur_entry <= best.t) {  // the closest hit may have moved in front of this box since it was stacked
+            if (COUNT) cnt.prims++;
+            consider<MEDIA>(S, W.cur & ~V4R_LEAF_BIT, o, d, best, key);
+        }
+        wide_pop(st, best.t, W);
+    }
+}
+
 template <bool COUNT, bool MEDIA, class KeyFn>
 V4R_DEV void traverse(const SceneDev &S, V3 o, V3 d, bool active, Stack &st, Best &best, TraceCounters &cnt, KeyFn key) {
     best.t = V4R_INF;
@@ -395,21 +390,21 @@ V4R_DEV void traverse(const SceneDev &S, V3 o, V3 d, bool active, Stack &st, Bes
         return;
     }
     V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    Trav T;
-    T.clear();
-    if (active) T.start();
+    Wide W;
+    W.clear();
+    if (active) W.start();
     st.sp = 0;
     while (true) {
         while (true) {
-            unsigned long long m_step = __ballot(T.stepping());
+            unsigned long long m_step = __ballot(W.stepping());
             if (m_step == 0ull) break;
-            unsigned long long m_parked = __ballot(T.parked());
+            unsigned long long m_parked = __ballot(W.parked());
             if (m_parked != 0ull && __popcll(m_parked) * V4R_VOTE_DEN >= (__popcll(m_parked) + __popcll(m_step)) * V4R_VOTE_NUM) break;
             if (COUNT) cnt.wave_steps++;
-            if (T.stepping()) trav_step<COUNT>(S, o, inv, st, best, T, cnt);
+            if (W.stepping()) wide_step<COUNT>(S, o, inv, st, best, W, cnt);
         }
-        if (__ballot(T.parked()) != 0ull) trav_leaves<COUNT, MEDIA>(S, o, d, st, best, T, cnt, key);
-        if (__ballot(T.node != TRAV_NONE) == 0ull) break;
+        if (__ballot(W.parked()) != 0ull) wide_leaves<COUNT, MEDIA>(S, o, d, st, best, W, cnt, key);
+        if (__ballot(W.cur != TRAV_NONE) == 0ull) break;
     }
 }
 
