@@ -29,7 +29,7 @@ sys.path.insert(0, os.path.join(ROOT, "ray-tracing_amd"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 # Bytes of the traversal kernel per unit of work (the record sizes of its queues and tables):
-RAY_RECORD, HIT_RECORD, NODE, PRIM, RADIANCE = 48, 64, 128, 48, 16
+RAY_RECORD, HIT_RECORD, NODE, PRIM, RADIANCE = 48, 20, 128, 48, 16
 
 
 def parse():
@@ -48,8 +48,9 @@ def parse():
 
 
 def trace_bytes(stats):
-    """Algorithmic bytes of k_trace for the counted work: one 48-B ray record read per segment, 128 B per 4-wide BVH
-    node and 48 B per primitive fetched, one 64-B hit record written per hit and one 16-B radiance write per miss."""
+    """Algorithmic bytes of k_trace for the counted work: one 48-B ray record per segment (read from the queue, or for a
+    camera ray that hits something written to it), 128 B per 4-wide BVH node and 48 B per primitive fetched, per hit a
+    16-B hit record + a 4-B class-queue index, per miss one 16-B radiance write."""
     hits = stats["shaded"]
     misses = stats["segments"] - hits
     return (stats["segments"] * RAY_RECORD + stats["nodes"] * NODE + stats["prims"] * PRIM + hits * HIT_RECORD

@@ -1,7 +1,7 @@
 // gfx950 wavefront path tracer: kernels and the C ABI of include/v4ray_hip.h.
 //
 // One batch = `P` full-image passes = P*W*H camera paths.  Per batch:
-//   k_raygen                       camera rays -> ray queue 0                (renderer.rs:94-122, camera.rs:113-129)
+//   k_trace<.., PRIMARY>(0)        camera rays generated in place + traced  (renderer.rs:94-122, camera.rs:113-129)
 //   for segment s = 0 .. max_depth-1:
 //     k_trace(s)                   BVH traversal + closest hit; misses write background;
 //                                  hits are binned by material class into hit queues (wave64
@@ -39,7 +39,7 @@ constexpr int TRACE_RAYS_PER_THREAD = V4R_TRACE_RAYS_PER_THREAD;
 
 // Per-segment queue counters, zeroed once per batch.
 struct SegCtr {
-    uint32_t ray_count;     // rays queued for k_trace of this segment
+    uint32_t reserved0;
     uint32_t trace_cursor;  // next ray index a wave of k_trace takes
     uint32_t hit_count[CLS_COUNT];
     uint32_t shade_cursor[CLS_COUNT];
@@ -49,8 +49,8 @@ static_assert(sizeof(SegCtr) == 64, "SegCtr is one 64-byte line");
 
 struct Queues {
     float4 *ray[2][3];          // [segment parity][column]: {o.xyz,d.x} {d.yz,thr.rg} {thr.b,slot,k0,k1}
-    float4 *hit[CLS_COUNT][4];  // the three ray columns + {t, prim, u, v}
-    float4 *hitd;               // {t, prim, u, v} of ray i of the segment being traced (staging for the class queues)
+    uint32_t *hit[CLS_COUNT];   // per shading class: the indices (into the ray queue of the segment) of the rays that hit it
+    float4 *hitd;               // {t, prim, u, v} of ray i of the segment being traced
     float4 *rad;                // per path slot: radiance of the finished path
     SegCtr *ctr;                // [max_depth + 1]
     uint2 *spill;               // traversal stack overflow, [entry][global thread]
@@ -173,30 +173,9 @@ V4R_DEV void ray_order(const RayOrder &R, uint32_t width, uint32_t npix, uint32_
     pixel = y * width + x;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_raygen(SceneDev S, Queues Q, uint32_t seed_lo, uint32_t seed_hi,
-                                                  uint32_t first_pass, uint32_t pass_stride, uint32_t n_paths, RayOrder order) {
-    uint32_t npix = S.width * S.height;
-    uint32_t stride = gridDim.x * BLOCK;
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n_paths; i += stride) {
-        uint32_t b, pixel;
-        ray_order(order, S.width, npix, i, b, pixel);
-        PathState p;
-        path_key(seed_lo, seed_hi, first_pass + b * pass_stride, pixel, p.k0, p.k1);
-        camera_ray(S, pixel, segment_key(p.k0, p.k1, 0), false, p.o, p.d);
-        p.thr = v3(1, 1, 1);
-        p.slot = b * npix + pixel;
-        store_ray(Q.ray[0], i, p);
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        Q.ctr[0].ray_count = n_paths;
-        if (Q.stats) atomicAdd(&Q.stats[3], (unsigned long long)n_paths);
-    }
-}
-
-// Rays queued for segment `seg`: the camera rays for segment 0, afterwards one ray per hit that the
-// scattering classes of the previous segment shaded (lights never scatter, diffuse_light.rs).
+// Rays queued for segment `seg` >= 1: one ray per hit that the scattering classes of the previous
+// segment shaded (lights never scatter, diffuse_light.rs).  Segment 0 traces one camera ray per path slot.
 V4R_DEV uint32_t rays_in(const Queues &Q, uint32_t seg) {
-    if (seg == 0) return Q.ctr[0].ray_count;
     const SegCtr &prev = Q.ctr[seg - 1u];
     uint32_t n = 0;
 #pragma unroll
@@ -229,8 +208,13 @@ V4R_DEV uint32_t class_base(const Queues &Q, uint32_t seg, int cls) {
 #ifndef V4R_TRACE_MIN_WAVES
 #define V4R_TRACE_MIN_WAVES 1
 #endif
-template <bool COUNT, int RAYS_PER_THREAD, bool MEDIA>
-__global__ __launch_bounds__(BLOCK, V4R_TRACE_MIN_WAVES) void k_trace(SceneDev S, Queues Q, uint32_t seg) {
+// Arguments of the first segment's launch, which generates the camera rays itself (PRIMARY).
+struct PrimaryArgs {
+    uint32_t seed_lo, seed_hi, first_pass, pass_stride, n_paths;
+    RayOrder order;
+};
+template <bool COUNT, int RAYS_PER_THREAD, bool MEDIA, bool PRIMARY>
+__global__ __launch_bounds__(BLOCK, V4R_TRACE_MIN_WAVES) void k_trace(SceneDev S, Queues Q, uint32_t seg, PrimaryArgs A) {
     __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
 #ifdef V4R_LDS_PAD
     __shared__ uint32_t lds_pad[V4R_LDS_PAD / 4];
@@ -246,8 +230,9 @@ __global__ __launch_bounds__(BLOCK, V4R_TRACE_MIN_WAVES) void k_trace(SceneDev S
     st.spill_stride = Q.spill_stride;
     st.sp = 0;
     SegCtr *ctr = Q.ctr + seg;
-    const uint32_t n_in = rays_in(Q, seg);
+    const uint32_t n_in = PRIMARY ? A.n_paths : rays_in(Q, seg);
     float4 *const *rq = Q.ray[seg & 1u];
+    const uint32_t npix = S.width * S.height;
     TraceCounters cnt;
     uint32_t n_traced = 0;
     bool started = false;
@@ -270,15 +255,34 @@ __global__ __launch_bounds__(BLOCK, V4R_TRACE_MIN_WAVES) void k_trace(SceneDev S
                 uint32_t i = base + j * BLOCK + threadIdx.x;
                 bool active = i < n_in;
                 uint32_t ii = active ? i : n_in - 1u;
-                float4 a = rq[0][ii];
-                float2 b = *reinterpret_cast<const float2 *>(&rq[1][ii]);
-                V3 o = v3(a.x, a.y, a.z), d = v3(a.w, b.x, b.y);
+                V3 o, d;
+                uint32_t pass_in_batch = 0, pixel = 0;  // PRIMARY only
+                if (PRIMARY) {
+                    // Renderer::sample + Camera::get_ray for queue entry ii (see ray_order); the ray record is
+                    // written further down, and only if the ray hits something: a miss ends the path here
+                    ray_order(A.order, S.width, npix, ii, pass_in_batch, pixel);
+                    uint32_t k0, k1;
+                    path_key(A.seed_lo, A.seed_hi, A.first_pass + pass_in_batch * A.pass_stride, pixel, k0, k1);
+                    camera_ray(S, pixel, segment_key(k0, k1, 0u), false, o, d);
+                } else {
+                    float4 a = rq[0][ii];
+                    float2 b = *reinterpret_cast<const float2 *>(&rq[1][ii]);
+                    o = v3(a.x, a.y, a.z);
+                    d = v3(a.w, b.x, b.y);
+                }
                 Best best;
                 if (COUNT && active) n_traced++;
                 // the random stream of the segment, needed only if the ray meets a constant medium
                 auto key = [&]() {
-                    float4 c = rq[2][ii];
-                    return segment_key(__float_as_uint(c.z), __float_as_uint(c.w), seg);
+                    uint32_t k0, k1;
+                    if (PRIMARY) {
+                        path_key(A.seed_lo, A.seed_hi, A.first_pass + pass_in_batch * A.pass_stride, pixel, k0, k1);
+                    } else {
+                        float4 c = rq[2][ii];
+                        k0 = __float_as_uint(c.z);
+                        k1 = __float_as_uint(c.w);
+                    }
+                    return segment_key(k0, k1, seg);
                 };
                 traverse<COUNT, MEDIA>(S, o, d, active, st, best, cnt, key);
                 uint32_t w = 0xFFFFFFFFu;
@@ -287,7 +291,18 @@ __global__ __launch_bounds__(BLOCK, V4R_TRACE_MIN_WAVES) void k_trace(SceneDev S
                         uint32_t cls = S.prim_info[best.prim] >> 24;
                         Q.hitd[i] = make_float4(best.t, __uint_as_float(best.prim), best.u, best.v);
                         w = (cls << 16) | atomicAdd(&s_cnt[cls], 1u);
-                    } else {  // renderer.rs:184: a miss takes the background colour
+                        if (PRIMARY) {
+                            PathState p;
+                            p.o = o;
+                            p.d = d;
+                            p.thr = v3(1, 1, 1);
+                            p.slot = pass_in_batch * npix + pixel;
+                            path_key(A.seed_lo, A.seed_hi, A.first_pass + pass_in_batch * A.pass_stride, pixel, p.k0, p.k1);
+                            store_ray(rq, i, p);
+                        }
+                    } else if (PRIMARY) {  // renderer.rs:184: a miss takes the background colour
+                        Q.rad[pass_in_batch * npix + pixel] = make_float4(S.bg[0], S.bg[1], S.bg[2], 0.0f);
+                    } else {
                         float4 bb = rq[1][i], c = rq[2][i];
                         Q.rad[__float_as_uint(c.y)] = make_float4(bb.z * S.bg[0], bb.w * S.bg[1], c.x * S.bg[2], 0.0f);
                     }
@@ -307,10 +322,7 @@ __global__ __launch_bounds__(BLOCK, V4R_TRACE_MIN_WAVES) void k_trace(SceneDev S
             uint32_t w = i < n_in ? s_where[j * BLOCK + threadIdx.x] : 0xFFFFFFFFu;  // slots past the queue end were never traced
             if (w != 0xFFFFFFFFu) {
                 uint32_t k = w >> 16, idx = s_cnt[k] + (w & 0xFFFFu);
-                Q.hit[k][0][idx] = rq[0][i];
-                Q.hit[k][1][idx] = rq[1][i];
-                Q.hit[k][2][idx] = rq[2][i];
-                Q.hit[k][3][idx] = Q.hitd[i];
+                Q.hit[k][idx] = i;
             }
         }
         __syncthreads();
@@ -324,6 +336,7 @@ __global__ __launch_bounds__(BLOCK, V4R_TRACE_MIN_WAVES) void k_trace(SceneDev S
             atomicAdd(&Q.stats[6], (unsigned long long)cnt.wave_steps);
             atomicAdd(&Q.stats[7], (unsigned long long)cnt.wave_leaves);
         }
+        if (PRIMARY && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&Q.stats[3], (unsigned long long)A.n_paths);
     }
 }
 
@@ -334,7 +347,8 @@ template <int CLS, bool COUNT>
 __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, Queues Q, uint32_t seg) {
     SegCtr *ctr = Q.ctr + seg;
     const uint32_t n_in = ctr->hit_count[CLS];
-    float4 *const *hq = Q.hit[CLS];
+    const uint32_t *hq = Q.hit[CLS];
+    float4 *const *rq = Q.ray[seg & 1u];  // the rays k_trace just traced; the survivors go to the other queue
     float4 *const *out = Q.ray[(seg + 1u) & 1u];
     const bool last = seg + 1u >= S.max_depth;
     const uint32_t out_base = class_base(Q, seg, CLS);
@@ -345,8 +359,9 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, Queues Q, uint32_t 
         uint32_t i = base + lane_id();
         bool valid = i < n_in;
         uint32_t ii = valid ? i : n_in - 1u;
-        PathState p = unpack_ray(hq[0][ii], hq[1][ii], hq[2][ii]);
-        float4 dcol = hq[3][ii];
+        uint32_t src = hq[ii];
+        PathState p = unpack_ray(rq[0][src], rq[1][src], rq[2][src]);
+        float4 dcol = Q.hitd[src];
         float t = dcol.x;
         uint32_t prim = __float_as_uint(dcol.y);
         const uint32_t *m = S.materials + 8 * (size_t)(S.prim_info[prim] & 0xFFFFFFu);
@@ -859,8 +874,7 @@ int ensure_pipe(v4r_renderer *r, Pipe &pipe, size_t need) {
         for (int c = 0; c < 3; ++c)
             if (int rc = alloc(&Q.ray[p][c], need)) return rc;
     for (int k = 0; k < CLS_COUNT; ++k)
-        for (int c = 0; c < 4; ++c)
-            if (int rc = alloc(&Q.hit[k][c], r->has_class[k] ? need : 1)) return rc;
+        if (int rc = alloc(&Q.hit[k], r->has_class[k] ? need : 1)) return rc;
     if (int rc = alloc(&Q.hitd, need)) return rc;
     if (int rc = alloc(&Q.rad, need)) return rc;
     if (int rc = alloc(&Q.ctr, (size_t)r->max_depth + 1)) return rc;
@@ -947,11 +961,11 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     }
     r->batch_passes = (uint32_t)std::max<size_t>(1, std::min<size_t>(target / r->npix, 4096));
     if ((uint64_t)r->batch_passes * r->npix > 0x7FFFFFFFull) r->batch_passes = (uint32_t)(0x7FFFFFFFull / r->npix);
-    if (r->batch_passes >= 16u) r->batch_passes &= ~15u;  // whole groups of passes for the tiled ray order of k_raygen
+    if (r->batch_passes >= 16u) r->batch_passes &= ~15u;  // whole groups of passes for the tiled order of the camera rays
     uint32_t n_pipes = 3;
     if (const char *env = std::getenv("V4R_PIPES")) n_pipes = (uint32_t)std::max(1, std::min(4, std::atoi(env)));
-    r->grid_trace = r->has_media ? std::max(grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, true>, n_cu), grid_for(k_trace_rays<true>, n_cu))
-                                 : std::max(grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, false>, n_cu), grid_for(k_trace_rays<false>, n_cu));
+    r->grid_trace = r->has_media ? std::max(std::max(grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, true, false>, n_cu), grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, true, true>, n_cu)), grid_for(k_trace_rays<true>, n_cu))
+                                 : std::max(std::max(grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, false, false>, n_cu), grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, false, true>, n_cu)), grid_for(k_trace_rays<false>, n_cu));
     r->grid_shade = (uint32_t)n_cu * 8u;
     r->grid_stream = (uint32_t)n_cu * 8u;
     // a ray's stack holds at most three entries per level of the wide tree above its current node
@@ -982,15 +996,20 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     return V4R_OK;
 }
 
-void launch_trace(v4r_renderer *r, Pipe &pipe, uint32_t seg) {
+void launch_trace(v4r_renderer *r, Pipe &pipe, uint32_t seg, const PrimaryArgs &A) {
     dim3 grid(r->grid_trace), block(BLOCK);
     constexpr int R = TRACE_RAYS_PER_THREAD;
-    if (r->has_media) {
-        if (r->counting) hipLaunchKernelGGL((k_trace<true, R, true>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg);
-        else hipLaunchKernelGGL((k_trace<false, R, true>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg);
-    } else {
-        if (r->counting) hipLaunchKernelGGL((k_trace<true, R, false>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg);
-        else hipLaunchKernelGGL((k_trace<false, R, false>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg);
+    // instantiations: work counters x constant media x (segment 0 generates its camera rays)
+    int which = (r->counting ? 4 : 0) | (r->has_media ? 2 : 0) | (seg == 0 ? 1 : 0);
+    switch (which) {
+        case 0: hipLaunchKernelGGL((k_trace<false, R, false, false>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A); break;
+        case 1: hipLaunchKernelGGL((k_trace<false, R, false, true>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A); break;
+        case 2: hipLaunchKernelGGL((k_trace<false, R, true, false>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A); break;
+        case 3: hipLaunchKernelGGL((k_trace<false, R, true, true>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A); break;
+        case 4: hipLaunchKernelGGL((k_trace<true, R, false, false>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A); break;
+        case 5: hipLaunchKernelGGL((k_trace<true, R, false, true>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A); break;
+        case 6: hipLaunchKernelGGL((k_trace<true, R, true, false>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A); break;
+        default: hipLaunchKernelGGL((k_trace<true, R, true, true>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A); break;
     }
 }
 
@@ -1002,8 +1021,6 @@ void launch_shade(v4r_renderer *r, Pipe &pipe, uint32_t seg) {
 }
 
 int run_batch(v4r_renderer *r, Pipe &pipe, uint64_t seed, uint32_t first_pass, uint32_t pass_stride, uint32_t n_batch_passes) {
-    Queues Q = pipe.Q;
-    if (!r->counting) Q.stats = nullptr;
     uint32_t n_paths = n_batch_passes * r->npix;
     HIP_TRY(hipMemsetAsync(pipe.Q.ctr, 0, r->ctr_bytes, pipe.stream));
     RayOrder order;
@@ -1020,8 +1037,7 @@ int run_batch(v4r_renderer *r, Pipe &pipe, uint64_t seed, uint32_t first_pass, u
         order.npix_tiled = order.tiled_w * order.tiled_h;
         order.full_groups = n_batch_passes >> lp;
     }
-    hipLaunchKernelGGL(k_raygen, dim3(r->grid_stream), dim3(BLOCK), 0, pipe.stream, r->S, Q, (uint32_t)seed, (uint32_t)(seed >> 32),
-                       first_pass, pass_stride, n_paths, order);
+    PrimaryArgs primary{(uint32_t)seed, (uint32_t)(seed >> 32), first_pass, pass_stride, n_paths, order};
     for (uint32_t seg = 0; seg < r->S.max_depth; ++seg) {
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         if (r->profiling) {
@@ -1036,7 +1052,7 @@ int run_batch(v4r_renderer *r, Pipe &pipe, uint64_t seed, uint32_t first_pass, u
             ev1 = r->ev_pool[r->ev_used++];
             HIP_TRY(hipEventRecord(ev0, pipe.stream));
         }
-        launch_trace(r, pipe, seg);
+        launch_trace(r, pipe, seg, primary);
         if (r->profiling) HIP_TRY(hipEventRecord(ev1, pipe.stream));
         launch_shade<CLS_LIGHT>(r, pipe, seg);
         launch_shade<CLS_LAMBERT>(r, pipe, seg);
