@@ -190,6 +190,8 @@ def main():
         achieved = bytes_per_step * args.steps / (trace_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": "k_trace", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "note": "algorithmic bytes are mostly BVH nodes and primitives served by L1/L2 (tables <= 15 MB), so "
+                            "achieved can exceed the HBM peak; traffic = HBM bytes per launch from rocprofv3 PMC",
                     "avg_launch_us": round(trace_ms * 1e3 / trace_launches, 3), "launches": trace_launches,
                     "kernel_ms_per_step": round(trace_ms / args.steps, 3),
                     "algorithmic_bytes_per_path": round(bytes_per_step / (npix * spp), 2),

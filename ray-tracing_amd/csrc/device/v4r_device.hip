@@ -1,18 +1,21 @@
 // gfx950 wavefront path tracer: kernels and the C ABI of include/v4ray_hip.h.
 //
-// One batch = `P` full-image passes = P*W*H camera paths.  Per batch:
-//   k_trace<.., PRIMARY>(0)        camera rays generated in place + traced  (renderer.rs:94-122, camera.rs:113-129)
+// One batch = `P` full-image passes = P*W*H camera paths.  Per batch, on one of the renderer's streams:
 //   for segment s = 0 .. max_depth-1:
-//     k_trace(s)                   BVH traversal + closest hit; misses write background;
-//                                  hits are binned by material class into hit queues (wave64
-//                                  ballot + prefix rank, one atomic per wave and class)
-//     k_shade<class>(s)            per-class material evaluation -> next ray queue
+//     k_trace(s)                   s = 0: camera rays generated in place (renderer.rs:94-122,
+//                                  camera.rs:113-129); s > 0: rays read from the queue the shading
+//                                  kernels filled.  4-wide BVH traversal + closest hit; a miss writes
+//                                  the path's radiance (background); a hit is ranked within its
+//                                  material class in LDS and its ray index is appended to the class
+//                                  queue (one global atomic per class per 1024-ray chunk)
+//     k_shade<class>(s)            per-class material evaluation; the scattered ray goes to slot
+//                                  class_base + i of the other ray queue (no atomics)
 //   k_resolve                      per-pixel sum of the batch's path radiances into the accumulator
 //
-// Queue records are 16-byte columns (structure of float4 arrays), so every queue access of a wave
-// is one contiguous 1 KiB transaction per column.  A path's radiance is written exactly once,
-// when it terminates (miss, light, depth exhausted), into a per-path slot; k_resolve adds the
-// slots of a pixel in ascending pass order, which keeps the image bit-reproducible.
+// Queue records are 16-byte columns (structure of float4 arrays), so a wave's access to consecutive
+// queue entries is one contiguous 1 KiB transaction per column.  A path's radiance is written
+// exactly once, when it terminates (miss, light, depth exhausted), into a per-path slot; k_resolve
+// adds the slots of a pixel in ascending pass order, which keeps the image bit-reproducible.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
