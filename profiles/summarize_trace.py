@@ -22,7 +22,8 @@ span = (ks[-1][1] - ks[0][0]) / 1e3
 print(f"span {span/1e3:.2f} ms, kernels busy {sum(v[1] for v in tot.values())/1e3:.2f} ms")
 for n, (c, us) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
     print(f"  {n:34s} calls {c:6d} total {us/1e3:9.2f} ms avg {us/c:9.2f} us")
-idx = [i for i, k in enumerate(ks) if "k_raygen" in k[2]]
+# a batch starts with the trace launch that generates the camera rays (last template argument true)
+idx = [i for i, k in enumerate(ks) if re.match(r"k_trace<.*, true>$", k[2])]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else len(idx) // 2
 if len(idx) > which + 1:
     i0, i1 = idx[which], idx[which + 1]
@@ -33,4 +34,7 @@ if len(idx) > which + 1:
         sh = [round((e - s) / 1e3, 1) for s, e, n in ks[i0:i1] if n == cls]
         print(f" {cls}:", sh[:10], "... sum", round(sum(sh), 1))
     gaps = sum(ks[i + 1][0] - ks[i][1] for i in range(i0, i1 - 1)) / 1e3
-    print(" idle gaps between kernels:", round(gaps, 1), "us")
+    if gaps < 0:
+        print(" (kernels of several streams overlap in this trace: the per-batch view above mixes batches; profile with V4R_PIPES=1 for a clean timeline)")
+    else:
+        print(" idle gaps between kernels:", round(gaps, 1), "us")
