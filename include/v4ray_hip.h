@@ -143,6 +143,11 @@ typedef struct v4r_camera {
                                            light (textbook); default off = the reference's packet
                                            behaviour (aa_rect.rs:158-179, triangle.rs:110-131)   */
 
+#define V4R_FLAG_KEEP_HOST_BVH 0x2u     /* traverse the topology of `nodes` as given (widened 2 -> 4);
+                                           default off = the device library re-splits the same leaf
+                                           boxes with a binned surface-area heuristic first, which
+                                           changes how many nodes a ray visits, never what it hits */
+
 /* Flattened scene + renderer parameters.  All pointers are host pointers, copied by
  * v4r_renderer_create; a table with n == 0 may be NULL. */
 typedef struct v4r_scene_desc {

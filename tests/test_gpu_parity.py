@@ -3,6 +3,7 @@ import numpy as np
 import pytest
 
 import oracle
+from v4ray_hip import _abi
 from v4ray_hip import (Dielectric, Lambertian, Metal, PerspectiveCameraParam, Renderer, RendererParam, Scene,
                        SolidColor, Sphere, scenes)
 
@@ -255,7 +256,8 @@ def test_tonemap_matches_host_arithmetic():
 def test_work_counters_match_oracle(name):
     """Nodes fetched / primitives tested / segments per path, counted by the instrumented trace kernel,
     agree with the oracle running the same traversal order (they feed the roofline's algorithmic bytes)."""
-    scene, r = make(name)
+    # same tree topology on both sides: the device re-splits the host's tree by default
+    scene, r = make(name, flags=_abi.V4R_FLAG_KEEP_HOST_BVH)
     r.enable_stats(True)
     r.render_passes(2)
     dev = r.read_stats(reset=True)
