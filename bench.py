@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mpaths/s of the render-loop hot path on N MI355X GPUs of one node.
 
-Workload (config.workload): BASELINE.json configs[1] by default -- the Book-1 random-spheres scene at
+Workload (config.workload): by default the Book-1 random-spheres scene (c2) at
 1920x1080, 256 samples per pixel per GPU.  One "step" renders those 256 full-image 1-spp passes on every
 rank (rank r takes passes r, r+N, r+2N, ... of one N*256-spp job, so per-GPU work is fixed: weak scaling)
 and, for N > 1, sums the per-GPU radiance accumulators onto rank 0 with one RCCL reduce over xGMI.
@@ -132,7 +132,8 @@ def main():
     fw, fh, fspp = scenes.FULL_SIZE[args.workload]
     width, height = args.width or fw, args.height or fh
     spp = args.spp or fspp
-    # the bunny's mesh transform is baked into its triangles on the host (same geometry)
+    # the bunny's mesh transform is baked into its triangles on the host: the same geometry without a per-test
+    # ray transform (tests/test_gpu_parity.py::test_primary_hits_pretransformed_bunny checks ids and t)
     scene = scenes.load(args.workload, width, height, pretransform_triangles=True)
     r = Renderer(scene.renderer_param, scene.camera_param, scene, device=local_rank)
     npix = width * height
