@@ -42,11 +42,11 @@ constexpr int TRACE_RAYS_PER_THREAD = V4R_TRACE_RAYS_PER_THREAD;
 
 // Per-segment queue counters, zeroed once per batch.
 struct SegCtr {
-    uint32_t reserved0;
-    uint32_t trace_cursor;  // next ray index a wave of k_trace takes
+    uint32_t given_up;      // rays the first trace launch of the segment left for the second
+    uint32_t trace_cursor;  // next chunk of the ray queue that a workgroup of the first launch takes
     uint32_t hit_count[CLS_COUNT];
-    uint32_t shade_cursor[CLS_COUNT];
-    uint32_t pad[2];
+    uint32_t second_cursor;  // trace_cursor of the second launch
+    uint32_t pad[7];
 };
 static_assert(sizeof(SegCtr) == 64, "SegCtr is one 64-byte line");
 
@@ -54,6 +54,7 @@ struct Queues {
     float4 *ray[2][3];          // [segment parity][column]: {o.xyz,d.x} {d.yz,thr.rg} {thr.b,slot,k0,k1}
     uint32_t *hit[CLS_COUNT];   // per shading class: the indices (into the ray queue of the segment) of the rays that hit it
     float4 *hitd;               // {t, prim, u, v} of ray i of the segment being traced
+    uint32_t *given_up;         // indices of the rays whose wave gave them up (see traverse); traced by a second launch
     float4 *rad;                // per path slot: radiance of the finished path
     SegCtr *ctr;                // [max_depth + 1]
     uint2 *spill;               // traversal stack overflow, [entry][global thread]
@@ -216,15 +217,21 @@ struct PrimaryArgs {
     uint32_t seed_lo, seed_hi, first_pass, pass_stride, n_paths;
     RayOrder order;
 };
-template <bool COUNT, int RAYS_PER_THREAD, bool MEDIA, bool PRIMARY>
-__global__ __launch_bounds__(BLOCK, V4R_TRACE_MIN_WAVES) void k_trace(SceneDev S, Queues Q, uint32_t seg, PrimaryArgs A) {
+// A segment is traced by up to two launches.  In the first, a wave that is down to `give_up_lanes`
+// traversing lanes gives those rays up (their indices go to Q.given_up, through the same chunk-level
+// ranking as the hits); the second launch (SECOND) traces the given-up rays of the whole
+// segment packed next to each other, starting from the closest hit they had found, and never gives up.
+// (SECOND is a template parameter because the extra index it carries costs the first launch an occupancy step.)
+template <bool COUNT, int RAYS_PER_THREAD, bool MEDIA, bool PRIMARY, bool SECOND>
+__global__ __launch_bounds__(BLOCK, V4R_TRACE_MIN_WAVES) void k_trace(SceneDev S, Queues Q, uint32_t seg, PrimaryArgs A, uint32_t give_up_lanes) {
+    constexpr bool second = SECOND;
     __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
 #ifdef V4R_LDS_PAD
     __shared__ uint32_t lds_pad[V4R_LDS_PAD / 4];
     if (seg == 0xFFFFFFFFu) lds_pad[threadIdx.x] = 1, Q.stats[threadIdx.x] = lds_pad[threadIdx.x ^ 1];
 #endif
     __shared__ uint32_t s_base;
-    __shared__ uint32_t s_cnt[CLS_COUNT];
+    __shared__ uint32_t s_cnt[CLS_COUNT + 1];  // [CLS_COUNT]: rays given up
     __shared__ uint32_t s_where[RAYS_PER_THREAD * BLOCK];  // per ray of the chunk: class << 16 | rank among the chunk's hits of that class
     Stack st;
     st.lds = (lds_uint2 *)lds_stack + threadIdx.x;
@@ -233,7 +240,7 @@ __global__ __launch_bounds__(BLOCK, V4R_TRACE_MIN_WAVES) void k_trace(SceneDev S
     st.spill_stride = Q.spill_stride;
     st.sp = 0;
     SegCtr *ctr = Q.ctr + seg;
-    const uint32_t n_in = PRIMARY ? A.n_paths : rays_in(Q, seg);
+    const uint32_t n_in = second ? ctr->given_up : (PRIMARY ? A.n_paths : rays_in(Q, seg));
     float4 *const *rq = Q.ray[seg & 1u];
     const uint32_t npix = S.width * S.height;
     TraceCounters cnt;
@@ -245,8 +252,8 @@ __global__ __launch_bounds__(BLOCK, V4R_TRACE_MIN_WAVES) void k_trace(SceneDev S
     const uint32_t chunk = per_thread * BLOCK;
     while (true) {
         if (threadIdx.x == 0)
-            s_base = started ? gridDim.x * chunk + atomicAdd(&ctr->trace_cursor, chunk) : blockIdx.x * chunk;
-        if (threadIdx.x < CLS_COUNT) s_cnt[threadIdx.x] = 0;
+            s_base = started ? gridDim.x * chunk + atomicAdd(second ? &ctr->second_cursor : &ctr->trace_cursor, chunk) : blockIdx.x * chunk;
+        if (threadIdx.x <= CLS_COUNT) s_cnt[threadIdx.x] = 0;
         started = true;
         __syncthreads();
         const uint32_t base = s_base;
@@ -255,9 +262,11 @@ __global__ __launch_bounds__(BLOCK, V4R_TRACE_MIN_WAVES) void k_trace(SceneDev S
         {
 #pragma unroll 1
             for (uint32_t j = 0; j < per_thread; ++j) {
-                uint32_t i = base + j * BLOCK + threadIdx.x;
-                bool active = i < n_in;
-                uint32_t ii = active ? i : n_in - 1u;
+                uint32_t pos = base + j * BLOCK + threadIdx.x;
+                bool active = pos < n_in;
+                uint32_t i = active ? pos : n_in - 1u;  // index of the ray in the queue of this segment
+                if (second) i = Q.given_up[i];
+                const uint32_t ii = i;
                 V3 o, d;
                 uint32_t pass_in_batch = 0, pixel = 0;  // PRIMARY only
                 if (PRIMARY) {
@@ -274,7 +283,16 @@ __global__ __launch_bounds__(BLOCK, V4R_TRACE_MIN_WAVES) void k_trace(SceneDev S
                     d = v3(a.w, b.x, b.y);
                 }
                 Best best;
-                if (COUNT && active) n_traced++;
+                best.t = V4R_INF;
+                best.prim = NO_PRIM;
+                best.u = best.v = 0.0f;
+                if (second) {  // the closest hit found before the ray was given up
+                    float4 h = Q.hitd[ii];
+                    best.t = h.x;
+                    best.prim = __float_as_uint(h.y);
+                    best.u = h.z;
+                    best.v = h.w;
+                }
                 // the random stream of the segment, needed only if the ray meets a constant medium
                 auto key = [&]() {
                     uint32_t k0, k1;
@@ -287,9 +305,13 @@ __global__ __launch_bounds__(BLOCK, V4R_TRACE_MIN_WAVES) void k_trace(SceneDev S
                     }
                     return segment_key(k0, k1, seg);
                 };
-                traverse<COUNT, MEDIA>(S, o, d, active, st, best, cnt, key);
+                bool gave_up = traverse<COUNT, MEDIA>(S, o, d, active, st, best, cnt, key, second ? 0u : give_up_lanes);
                 uint32_t w = 0xFFFFFFFFu;
-                if (active) {
+                if (active && gave_up) {
+                    Q.hitd[i] = make_float4(best.t, __uint_as_float(best.prim), best.u, best.v);
+                    w = ((uint32_t)CLS_COUNT << 16) | atomicAdd(&s_cnt[CLS_COUNT], 1u);
+                } else if (active) {
+                    if (COUNT) n_traced++;
                     if (best.prim != NO_PRIM) {
                         uint32_t cls = S.prim_info[best.prim] >> 24;
                         Q.hitd[i] = make_float4(best.t, __uint_as_float(best.prim), best.u, best.v);
@@ -314,18 +336,20 @@ __global__ __launch_bounds__(BLOCK, V4R_TRACE_MIN_WAVES) void k_trace(SceneDev S
             }
         }
         __syncthreads();
-        if (threadIdx.x < CLS_COUNT) {
+        if (threadIdx.x <= CLS_COUNT) {
             uint32_t n = s_cnt[threadIdx.x];
-            s_cnt[threadIdx.x] = n ? atomicAdd(&ctr->hit_count[threadIdx.x], n) : 0u;
+            uint32_t *total = threadIdx.x < CLS_COUNT ? &ctr->hit_count[threadIdx.x] : &ctr->given_up;
+            s_cnt[threadIdx.x] = n ? atomicAdd(total, n) : 0u;
         }
         __syncthreads();
 #pragma unroll 1
         for (uint32_t j = 0; j < per_thread; ++j) {
-            uint32_t i = base + j * BLOCK + threadIdx.x;
-            uint32_t w = i < n_in ? s_where[j * BLOCK + threadIdx.x] : 0xFFFFFFFFu;  // slots past the queue end were never traced
+            uint32_t pos = base + j * BLOCK + threadIdx.x;
+            uint32_t w = pos < n_in ? s_where[j * BLOCK + threadIdx.x] : 0xFFFFFFFFu;  // slots past the queue end were never traced
             if (w != 0xFFFFFFFFu) {
+                uint32_t i = second ? Q.given_up[pos] : pos;
                 uint32_t k = w >> 16, idx = s_cnt[k] + (w & 0xFFFFu);
-                Q.hit[k][idx] = i;
+                (k < (uint32_t)CLS_COUNT ? Q.hit[k] : Q.given_up)[idx] = i;
             }
         }
         __syncthreads();
@@ -541,7 +565,10 @@ __global__ __launch_bounds__(BLOCK) void k_trace_rays(SceneDev S, Queues Q, uint
             path_key(seed_lo, seed_hi, 0u, i, k0, k1);
             return segment_key(k0, k1, 0u);
         };
-        traverse<false, MEDIA>(S, o, d, valid, st, best, cnt, key);
+        best.t = V4R_INF;
+        best.prim = NO_PRIM;
+        best.u = best.v = 0.0f;
+        traverse<false, MEDIA>(S, o, d, valid, st, best, cnt, key, 0u);
         if (valid) {
             prim_out[i] = best.prim;
             t_out[i] = best.t;
@@ -600,6 +627,7 @@ struct v4r_renderer {
     uint64_t trace_launches = 0;
     bool has_class[CLS_COUNT] = {false, false, false, false, false, false};
     bool has_media = false;  // selects the kernels that carry the constant-medium test
+    uint32_t give_up_lanes = 0, give_up_segments = 0;  // see k_trace
     size_t ctr_bytes = 0;
     uint32_t max_depth = 0, spill_depth = 0;
 
@@ -1015,6 +1043,7 @@ int ensure_pipe(v4r_renderer *r, Pipe &pipe, size_t need) {
     for (int k = 0; k < CLS_COUNT; ++k)
         if (int rc = alloc(&Q.hit[k], r->has_class[k] ? need : 1)) return rc;
     if (int rc = alloc(&Q.hitd, need)) return rc;
+    if (int rc = alloc(&Q.given_up, need)) return rc;
     if (int rc = alloc(&Q.rad, need)) return rc;
     if (int rc = alloc(&Q.ctr, (size_t)r->max_depth + 1)) return rc;
     HIP_TRY(hipMemset(Q.ctr, 0, r->ctr_bytes));
@@ -1086,6 +1115,10 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     if (int rc = r->upload(&S.lights, d->lights, (size_t)d->n_lights)) return rc;
     S.n_nodes = d->n_nodes;
     r->has_media = d->n_media != 0;
+    r->give_up_lanes = 8;
+    r->give_up_segments = 8;
+    if (const char *env = std::getenv("V4R_GIVE_UP_LANES")) r->give_up_lanes = (uint32_t)std::max(0, std::min(63, std::atoi(env)));
+    if (const char *env = std::getenv("V4R_GIVE_UP_SEGMENTS")) r->give_up_segments = (uint32_t)std::max(0, std::atoi(env));
     S.n_prims = d->n_prims;
     S.n_lights = d->n_lights;
     S.flags = d->flags;
@@ -1109,8 +1142,8 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     if (r->batch_passes >= 16u) r->batch_passes &= ~15u;  // whole groups of passes for the tiled order of the camera rays
     uint32_t n_pipes = 3;
     if (const char *env = std::getenv("V4R_PIPES")) n_pipes = (uint32_t)std::max(1, std::min(4, std::atoi(env)));
-    r->grid_trace = r->has_media ? std::max(std::max(grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, true, false>, n_cu), grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, true, true>, n_cu)), grid_for(k_trace_rays<true>, n_cu))
-                                 : std::max(std::max(grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, false, false>, n_cu), grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, false, true>, n_cu)), grid_for(k_trace_rays<false>, n_cu));
+    r->grid_trace = r->has_media ? std::max(std::max(grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, true, false, false>, n_cu), grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, true, true, false>, n_cu)), grid_for(k_trace_rays<true>, n_cu))
+                                 : std::max(std::max(grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, false, false, false>, n_cu), grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, false, true, false>, n_cu)), grid_for(k_trace_rays<false>, n_cu));
     r->grid_shade = (uint32_t)n_cu * 8u;
     r->grid_stream = (uint32_t)n_cu * 8u;
     // a ray's stack holds at most three entries per level of the wide tree above its current node
@@ -1146,15 +1179,29 @@ void launch_trace(v4r_renderer *r, Pipe &pipe, uint32_t seg, const PrimaryArgs &
     constexpr int R = TRACE_RAYS_PER_THREAD;
     // instantiations: work counters x constant media x (segment 0 generates its camera rays)
     int which = (r->counting ? 4 : 0) | (r->has_media ? 2 : 0) | (seg == 0 ? 1 : 0);
+    // the first segments hold nearly all rays: there a wave gives its last few rays up to a second launch
+    uint32_t give_up = seg < r->give_up_segments ? r->give_up_lanes : 0u;
+    auto launch = [&](auto kernel, uint32_t lanes) { hipLaunchKernelGGL(kernel, grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A, lanes); };
     switch (which) {
-        case 0: hipLaunchKernelGGL((k_trace<false, R, false, false>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A); break;
-        case 1: hipLaunchKernelGGL((k_trace<false, R, false, true>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A); break;
-        case 2: hipLaunchKernelGGL((k_trace<false, R, true, false>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A); break;
-        case 3: hipLaunchKernelGGL((k_trace<false, R, true, true>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A); break;
-        case 4: hipLaunchKernelGGL((k_trace<true, R, false, false>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A); break;
-        case 5: hipLaunchKernelGGL((k_trace<true, R, false, true>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A); break;
-        case 6: hipLaunchKernelGGL((k_trace<true, R, true, false>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A); break;
-        default: hipLaunchKernelGGL((k_trace<true, R, true, true>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A); break;
+        case 0: launch(k_trace<false, R, false, false, false>, give_up); break;
+        case 1: launch(k_trace<false, R, false, true, false>, give_up); break;
+        case 2: launch(k_trace<false, R, true, false, false>, give_up); break;
+        case 3: launch(k_trace<false, R, true, true, false>, give_up); break;
+        case 4: launch(k_trace<true, R, false, false, false>, give_up); break;
+        case 5: launch(k_trace<true, R, false, true, false>, give_up); break;
+        case 6: launch(k_trace<true, R, true, false, false>, give_up); break;
+        default: launch(k_trace<true, R, true, true, false>, give_up); break;
+    }
+    if (!give_up) return;
+    switch (which) {
+        case 0: launch(k_trace<false, R, false, false, true>, 0u); break;
+        case 1: launch(k_trace<false, R, false, true, true>, 0u); break;
+        case 2: launch(k_trace<false, R, true, false, true>, 0u); break;
+        case 3: launch(k_trace<false, R, true, true, true>, 0u); break;
+        case 4: launch(k_trace<true, R, false, false, true>, 0u); break;
+        case 5: launch(k_trace<true, R, false, true, true>, 0u); break;
+        case 6: launch(k_trace<true, R, true, false, true>, 0u); break;
+        default: launch(k_trace<true, R, true, true, true>, 0u); break;
     }
 }
 

@@ -376,36 +376,44 @@ V4R_DEV void wide_leaves(const SceneDev &S, V3 o, V3 d, Stack &st, Best &best, W
     }
 }
 
+// Closest hit of one ray per lane.  Must be called by every lane of the wave; lanes with
+// active == false only take part in the votes.  `best` comes in as the closest hit known so far
+// (none: t = +inf).  When at most `give_up_lanes` lanes of the wave are still traversing (and the wave
+// has made a few steps), those lanes give their rays up and the function returns true for them, with
+// the closest hit found so far in `best`: the caller queues such rays for a second launch in which
+// they sit next to each other instead of holding a nearly empty wave.  0 = never give up.
 template <bool COUNT, bool MEDIA, class KeyFn>
-V4R_DEV void traverse(const SceneDev &S, V3 o, V3 d, bool active, Stack &st, Best &best, TraceCounters &cnt, KeyFn key) {
-    best.t = V4R_INF;
-    best.prim = NO_PRIM;
-    best.u = best.v = 0.0f;
-    if (S.n_prims == 0) return;
+V4R_DEV bool traverse(const SceneDev &S, V3 o, V3 d, bool active, Stack &st, Best &best, TraceCounters &cnt, KeyFn key,
+                      uint32_t give_up_lanes) {
+    if (S.n_prims == 0) return false;
     if (S.n_nodes == 0) {  // single shape: tested without any box (bvh.rs:218-224)
         if (active) {
             if (COUNT) cnt.prims++;
             consider<MEDIA>(S, 0, o, d, best, key);
         }
-        return;
+        return false;
     }
     V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     Wide W;
     W.clear();
     if (active) W.start();
     st.sp = 0;
+    uint32_t steps = 0;
     while (true) {
         while (true) {
             unsigned long long m_step = __ballot(W.stepping());
             if (m_step == 0ull) break;
             unsigned long long m_parked = __ballot(W.parked());
+            if (give_up_lanes != 0u && steps >= 3u && (uint32_t)__popcll(m_step | m_parked) <= give_up_lanes) return W.cur != TRAV_NONE;
             if (m_parked != 0ull && __popcll(m_parked) * V4R_VOTE_DEN >= (__popcll(m_parked) + __popcll(m_step)) * V4R_VOTE_NUM) break;
             if (COUNT) cnt.wave_steps++;
+            ++steps;
             if (W.stepping()) wide_step<COUNT>(S, o, inv, st, best, W, cnt);
         }
         if (__ballot(W.parked()) != 0ull) wide_leaves<COUNT, MEDIA>(S, o, d, st, best, W, cnt, key);
         if (__ballot(W.cur != TRAV_NONE) == 0ull) break;
     }
+    return false;
 }
 
 // ---- hit reconstruction -------------------------------------------------------------------------

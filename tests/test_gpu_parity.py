@@ -221,6 +221,24 @@ def test_checkpoint_resume_is_bit_identical(tmp_path):
     r2.close()
 
 
+@pytest.mark.parametrize("name", ["c2", "c4", "c1"])
+def test_second_trace_launch_changes_nothing(name, monkeypatch):
+    """Rays that a nearly empty wave gives up are traced by a second launch, starting from the closest hit
+    found so far: the image is bit-identical with and without it, whatever the threshold."""
+    scene, r = make(name)
+    r.render_passes(3)
+    ref, _ = r.read_accumulator()
+    r.close()
+    for lanes, segs in (("0", "8"), ("32", "50"), ("63", "2")):
+        monkeypatch.setenv("V4R_GIVE_UP_LANES", lanes)
+        monkeypatch.setenv("V4R_GIVE_UP_SEGMENTS", segs)
+        r2 = Renderer(scene.renderer_param, scene.camera_param, scene)
+        r2.render_passes(3)
+        img, _ = r2.read_accumulator()
+        assert np.array_equal(img, ref), (lanes, segs)
+        r2.close()
+
+
 def test_sample_split_over_ranks_matches_single_rank():
     """Rank r of N renders passes r, r+N, ...: the per-rank sums add up to the single-rank image
     (to fp32 reassociation) because pass p draws the same random streams wherever it runs."""
@@ -253,10 +271,12 @@ def test_tonemap_matches_host_arithmetic():
 
 
 @pytest.mark.parametrize("name", ["c2", "c4"])
-def test_work_counters_match_oracle(name):
+def test_work_counters_match_oracle(name, monkeypatch):
     """Nodes fetched / primitives tested / segments per path, counted by the instrumented trace kernel,
     agree with the oracle running the same traversal order (they feed the roofline's algorithmic bytes)."""
-    # same tree topology on both sides: the device re-splits the host's tree by default
+    # same tree topology on both sides: the device re-splits the host's tree by default; and no second trace
+    # launch, whose given-up rays repeat part of their traversal
+    monkeypatch.setenv("V4R_GIVE_UP_LANES", "0")
     scene, r = make(name, flags=_abi.V4R_FLAG_KEEP_HOST_BVH)
     r.enable_stats(True)
     r.render_passes(2)
