@@ -9,7 +9,7 @@ from collections import defaultdict
 def short(n):
     n = re.sub(r"\(anonymous namespace\)::", "", n)
     n = re.sub(r"\((v4r::)?(SceneDev|\(anonymous).*", "", n)
-    return n.replace("void ", "")[:34]
+    return n.replace("void ", "")[:44]
 
 
 rows = list(csv.DictReader(open(sys.argv[1])))
@@ -21,9 +21,9 @@ for s, e, n in ks:
 span = (ks[-1][1] - ks[0][0]) / 1e3
 print(f"span {span/1e3:.2f} ms, kernels busy {sum(v[1] for v in tot.values())/1e3:.2f} ms")
 for n, (c, us) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
-    print(f"  {n:34s} calls {c:6d} total {us/1e3:9.2f} ms avg {us/c:9.2f} us")
+    print(f"  {n:44s} calls {c:6d} total {us/1e3:9.2f} ms avg {us/c:9.2f} us")
 # a batch starts with the trace launch that generates the camera rays (last template argument true)
-idx = [i for i, k in enumerate(ks) if re.match(r"k_trace<.*, true>$", k[2])]
+idx = [i for i, k in enumerate(ks) if re.match(r"k_trace<\w+, \d+, \w+, true, false>$", k[2])]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else len(idx) // 2
 if len(idx) > which + 1:
     i0, i1 = idx[which], idx[which + 1]
