@@ -262,6 +262,9 @@ struct Stack {
 #define V4R_VOTE_DEN 2
 #endif
 constexpr uint32_t TRAV_NONE = 0xFFFFFFFFu;
+#ifndef V4R_GIVE_UP_MIN_STEPS
+#define V4R_GIVE_UP_MIN_STEPS 3u  // node steps a wave makes before it may give rays up
+#endif
 
 // ---- traversal -------------------------------------------------------------------------------------
 // BVH::traverse (bvh/bvh.rs:182-239) + closest-hit selection (renderer.rs:149-183), restructured for a
@@ -404,7 +407,7 @@ V4R_DEV bool traverse(const SceneDev &S, V3 o, V3 d, bool active, Stack &st, Bes
             unsigned long long m_step = __ballot(W.stepping());
             if (m_step == 0ull) break;
             unsigned long long m_parked = __ballot(W.parked());
-            if (give_up_lanes != 0u && steps >= 3u && (uint32_t)__popcll(m_step | m_parked) <= give_up_lanes) return W.cur != TRAV_NONE;
+            if (give_up_lanes != 0u && steps >= V4R_GIVE_UP_MIN_STEPS && (uint32_t)__popcll(m_step | m_parked) <= give_up_lanes) return W.cur != TRAV_NONE;
             if (m_parked != 0ull && __popcll(m_parked) * V4R_VOTE_DEN >= (__popcll(m_parked) + __popcll(m_step)) * V4R_VOTE_NUM) break;
             if (COUNT) cnt.wave_steps++;
             ++steps;
