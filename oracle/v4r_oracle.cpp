@@ -387,6 +387,7 @@ void traverse_reference(Ctx &ctx, uint32_t node, const Ray &r, Closest &c) {
 struct WideNode {
     float lo[4][3], hi[4][3];
     uint32_t child[4];  // interior wide index, V4R_LEAF_BIT | primitive, or 0xFFFFFFFF for an empty slot
+    bool never_cull[4]; // the child's subtree holds a constant medium, whose hit may lie in front of its box entry
 };
 struct WideTree {
     std::vector<WideNode> nodes;
@@ -410,6 +411,26 @@ WideTree build_wide(const v4r_scene_desc *s) {
         a.child = n.child0;
         b.child = n.child1;
     };
+    // subtrees of the binary tree that hold a constant medium
+    std::vector<char> holds(s->n_nodes, 0);
+    auto is_medium = [&](uint32_t word) { return (s->prims[word & ~V4R_LEAF_BIT].type & V4R_PRIM_TYPE_MASK) == V4R_PRIM_MEDIUM; };
+    if (s->n_media) {
+        std::vector<std::pair<uint32_t, bool>> walk{{0u, false}};
+        while (!walk.empty()) {
+            auto [node, done] = walk.back();
+            walk.pop_back();
+            const v4r_bvh_node &n = s->nodes[node];
+            if (!done) {
+                walk.push_back({node, true});
+                if (!(n.child0 & V4R_LEAF_BIT)) walk.push_back({n.child0, false});
+                if (!(n.child1 & V4R_LEAF_BIT)) walk.push_back({n.child1, false});
+            } else {
+                bool a = (n.child0 & V4R_LEAF_BIT) ? is_medium(n.child0) : holds[n.child0] != 0;
+                bool b = (n.child1 & V4R_LEAF_BIT) ? is_medium(n.child1) : holds[n.child1] != 0;
+                holds[node] = a || b;
+            }
+        }
+    }
     std::vector<std::pair<uint32_t, uint32_t>> todo{{0u, 0u}};  // (binary node, wide node)
     w.nodes.resize(1);
     while (!todo.empty()) {
@@ -446,6 +467,7 @@ WideTree build_wide(const v4r_scene_desc *s) {
                 out.lo[k][a] = items[k].lo[a];
                 out.hi[k][a] = items[k].hi[a];
             }
+            out.never_cull[k] = s->n_media && ((items[k].child & V4R_LEAF_BIT) ? is_medium(items[k].child) : holds[items[k].child] != 0);
             if (items[k].child & V4R_LEAF_BIT) {
                 out.child[k] = items[k].child;
             } else {
@@ -485,14 +507,15 @@ void traverse_wide(Ctx &ctx, const WideTree &tree, const Ray &r, Closest &c) {
             uint32_t key[4];
             for (int k = 0; k < 4; ++k) {
                 float e = 0.0f;
-                bool hit = n.child[k] != 0xFFFFFFFFu && slab(n.lo[k], n.hi[k], r, EPSILON, INF, e) && e <= c.hit.t;
+                bool hit = n.child[k] != 0xFFFFFFFFu && slab(n.lo[k], n.hi[k], r, EPSILON, INF, e) && (e <= c.hit.t || n.never_cull[k]);
                 key[k] = hit ? ((bits(e) & ~3u) | (uint32_t)k) : 0xFFFFFFFFu;
             }
             std::sort(key, key + 4);
+            auto entry_of = [&](uint32_t k) { return n.never_cull[k & 3u] ? -INF : from_bits(k & ~3u); };
             for (int k = 3; k >= 1; --k)
-                if (key[k] != 0xFFFFFFFFu) stack.push_back({n.child[key[k] & 3u], from_bits(key[k] & ~3u)});
+                if (key[k] != 0xFFFFFFFFu) stack.push_back({n.child[key[k] & 3u], entry_of(key[k])});
             if (key[0] != 0xFFFFFFFFu) {
-                cur = {n.child[key[0] & 3u], from_bits(key[0] & ~3u)};
+                cur = {n.child[key[0] & 3u], entry_of(key[0])};
                 continue;
             }
         }

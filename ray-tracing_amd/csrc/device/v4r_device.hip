@@ -25,6 +25,7 @@
 #include <limits>
 #include <string>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "v4r_scene_dev.hpp"
@@ -935,9 +936,34 @@ void rebuild_binary(const v4r_scene_desc *d, std::vector<v4r_bvh_node> &out) {
 // by that child's two children.  Leaves stay single primitives, so the set of (ray, primitive) tests
 // that can happen is the one of the binary tree.  Nodes are emitted parent before children, siblings
 // next to each other.
-uint32_t collapse_to_wide(const v4r_bvh_node *nodes, uint32_t n_nodes, std::vector<float4> &out) {
+uint32_t collapse_to_wide(const v4r_scene_desc *d, const v4r_bvh_node *nodes, uint32_t n_nodes, std::vector<float4> &out) {
     out.clear();
     if (n_nodes == 0) return 0;
+    // which subtrees of the binary tree hold a constant medium (wide_step must not cull those by distance)
+    std::vector<uint8_t> holds_medium(n_nodes, 0);
+    if (d->n_media != 0) {
+        auto leaf_is_medium = [&](uint32_t word) { return (d->prims[word & ~V4R_LEAF_BIT].type & V4R_PRIM_TYPE_MASK) == V4R_PRIM_MEDIUM; };
+        std::vector<std::pair<uint32_t, bool>> walk{{0u, false}};  // (node, children done)
+        while (!walk.empty()) {
+            auto [node, done] = walk.back();
+            walk.pop_back();
+            const v4r_bvh_node &n = nodes[node];
+            if (!done) {
+                walk.push_back({node, true});
+                if (!(n.child0 & V4R_LEAF_BIT)) walk.push_back({n.child0, false});
+                if (!(n.child1 & V4R_LEAF_BIT)) walk.push_back({n.child1, false});
+            } else {
+                bool a = (n.child0 & V4R_LEAF_BIT) ? leaf_is_medium(n.child0) : holds_medium[n.child0] != 0;
+                bool b = (n.child1 & V4R_LEAF_BIT) ? leaf_is_medium(n.child1) : holds_medium[n.child1] != 0;
+                holds_medium[node] = a || b;
+            }
+        }
+    }
+    auto never_cull = [&](uint32_t word) {
+        if (d->n_media == 0) return false;
+        if (word & V4R_LEAF_BIT) return (d->prims[word & ~V4R_LEAF_BIT].type & V4R_PRIM_TYPE_MASK) == V4R_PRIM_MEDIUM;
+        return holds_medium[word] != 0;
+    };
     struct Item {
         float lo[3], hi[3];
         uint32_t child;  // word of the binary tree: interior index or V4R_LEAF_BIT | primitive
@@ -987,7 +1013,9 @@ uint32_t collapse_to_wide(const v4r_bvh_node *nodes, uint32_t n_nodes, std::vect
             ++n;
         }
         float lo[3][4], hi[3][4];
-        uint32_t child[4];
+        uint32_t child[4], mask = 0;
+        for (int k = 0; k < n; ++k)
+            if (never_cull(items[k].child)) mask |= 1u << k;
         for (int k = 0; k < 4; ++k) {
             for (int a = 0; a < 3; ++a) {
                 // NaN planes make every comparison of the slab test false (an inverted box would not: the test
@@ -1011,7 +1039,9 @@ uint32_t collapse_to_wide(const v4r_bvh_node *nodes, uint32_t n_nodes, std::vect
         float c[4];
         std::memcpy(c, child, 16);
         w[6] = make_float4(c[0], c[1], c[2], c[3]);
-        w[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float mask_bits;
+        std::memcpy(&mask_bits, &mask, 4);
+        w[7] = make_float4(mask_bits, 0.0f, 0.0f, 0.0f);
     }
     return depth;  // in wide nodes, root = 1
 }
@@ -1069,9 +1099,9 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
         if (!(d->flags & V4R_FLAG_KEEP_HOST_BVH) && d->n_nodes > 0) {
             std::vector<v4r_bvh_node> better;
             rebuild_binary(d, better);
-            wide_depth = collapse_to_wide(better.data(), (uint32_t)better.size(), wide);
+            wide_depth = collapse_to_wide(d, better.data(), (uint32_t)better.size(), wide);
         } else {
-            wide_depth = collapse_to_wide(d->nodes, d->n_nodes, wide);
+            wide_depth = collapse_to_wide(d, d->nodes, d->n_nodes, wide);
         }
         if (int rc = r->upload(&S.nodes4, wide.data(), wide.size())) return rc;
     }

@@ -283,7 +283,7 @@ constexpr uint32_t TRAV_NONE = 0xFFFFFFFFu;
 // only ever compared as `entry <= closest hit`, for which a slightly smaller entry is merely
 // conservative.
 //
-// Node layout (8 float4): lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4] child[4] pad[4]; an
+// Node layout (8 float4): lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4] child[4] {never-cull mask,-,-,-}; an
 // empty slot has NaN planes (never entered) and child word TRAV_NONE.
 struct Wide {
     uint32_t cur;      // interior node index, V4R_LEAF_BIT | primitive, or TRAV_NONE when finished / absent
@@ -312,11 +312,16 @@ V4R_DEV void wide_pop(Stack &st, float best_t, Wide &W) {
     }
 }
 
-template <bool COUNT>
+// A constant medium breaks the rule that lets far subtrees be skipped: its "hit" lies at entry + free path
+// along the whole line (constant_medium.rs:44-84), which may be in front of its box entry, even behind the
+// origin.  Children whose subtree holds a medium (bit k of the node's eighth float4) are therefore never
+// culled by distance: they are entered whenever the ray meets their box and carry entry distance -inf.
+template <bool COUNT, bool MEDIA>
 V4R_DEV void wide_step(const SceneDev &S, V3 o, V3 inv, Stack &st, const Best &best, Wide &W, TraceCounters &cnt) {
     const float4 *np = S.nodes4 + 8 * (size_t)W.cur;
     float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5];
     float4 kids = np[6];
+    const uint32_t never_cull = MEDIA ? __float_as_uint(np[7].x) : 0u;
     if (COUNT) cnt.nodes++;
     // Ray::intersects_aabb (ray.rs:167-189): the same running-interval test with strict tmin < tmax, the
     // per-axis divisions replaced by multiplications with a reciprocal computed once per ray; the interval
@@ -334,8 +339,9 @@ V4R_DEV void wide_step(const SceneDev &S, V3 o, V3 inv, Stack &st, const Best &b
         float e1 = fmaxf(fmaxf(fminf(ax0.y, ax1.y), fminf(ay0.y, ay1.y)), fmaxf(fminf(az0.y, az1.y), EPSILON));
         float f1 = fminf(fminf(fmaxf(ax0.y, ax1.y), fmaxf(ay0.y, ay1.y)), fmaxf(az0.y, az1.y));
         // entry distances are >= EPSILON > 0, so their bit patterns order like the floats
-        key[2 * h] = (e0 < f0 && e0 <= best.t) ? ((__float_as_uint(e0) & ~3u) | (uint32_t)(2 * h)) : 0xFFFFFFFFu;
-        key[2 * h + 1] = (e1 < f1 && e1 <= best.t) ? ((__float_as_uint(e1) & ~3u) | (uint32_t)(2 * h + 1)) : 0xFFFFFFFFu;
+        bool in0 = e0 <= best.t || (never_cull >> (2 * h) & 1u), in1 = e1 <= best.t || (never_cull >> (2 * h + 1) & 1u);
+        key[2 * h] = (e0 < f0 && in0) ? ((__float_as_uint(e0) & ~3u) | (uint32_t)(2 * h)) : 0xFFFFFFFFu;
+        key[2 * h + 1] = (e1 < f1 && in1) ? ((__float_as_uint(e1) & ~3u) | (uint32_t)(2 * h + 1)) : 0xFFFFFFFFu;
     }
     // sort the four keys ascending (5 compare-exchanges); missed children sort last
     auto cas = [&](int a, int b) {
@@ -353,13 +359,14 @@ V4R_DEV void wide_step(const SceneDev &S, V3 o, V3 inv, Stack &st, const Best &b
         float c = slot == 0u ? kids.x : (slot == 1u ? kids.y : (slot == 2u ? kids.z : kids.w));
         return __float_as_uint(c);
     };
+    auto entry_of = [&](uint32_t k) { return (never_cull >> (k & 3u) & 1u) ? -V4R_INF : __uint_as_float(k & ~3u); };
     // farther children first, so that the nearest of them is popped first
-    if (key[3] != 0xFFFFFFFFu) st.push(child_of(key[3]), __uint_as_float(key[3] & ~3u));
-    if (key[2] != 0xFFFFFFFFu) st.push(child_of(key[2]), __uint_as_float(key[2] & ~3u));
-    if (key[1] != 0xFFFFFFFFu) st.push(child_of(key[1]), __uint_as_float(key[1] & ~3u));
+    if (key[3] != 0xFFFFFFFFu) st.push(child_of(key[3]), entry_of(key[3]));
+    if (key[2] != 0xFFFFFFFFu) st.push(child_of(key[2]), entry_of(key[2]));
+    if (key[1] != 0xFFFFFFFFu) st.push(child_of(key[1]), entry_of(key[1]));
     if (key[0] != 0xFFFFFFFFu) {
         W.cur = child_of(key[0]);
-        W.cur_entry = __uint_as_float(key[0] & ~3u);
+        W.cur_entry = entry_of(key[0]);
     } else {
         wide_pop(st, best.t, W);
     }
@@ -411,7 +418,7 @@ V4R_DEV bool traverse(const SceneDev &S, V3 o, V3 d, bool active, Stack &st, Bes
             if (m_parked != 0ull && __popcll(m_parked) * V4R_VOTE_DEN >= (__popcll(m_parked) + __popcll(m_step)) * V4R_VOTE_NUM) break;
             if (COUNT) cnt.wave_steps++;
             ++steps;
-            if (W.stepping()) wide_step<COUNT>(S, o, inv, st, best, W, cnt);
+            if (W.stepping()) wide_step<COUNT, MEDIA>(S, o, inv, st, best, W, cnt);
         }
         if (__ballot(W.parked()) != 0ull) wide_leaves<COUNT, MEDIA>(S, o, d, st, best, W, cnt, key);
         if (__ballot(W.cur != TRAV_NONE) == 0ull) break;

@@ -4,8 +4,8 @@ import pytest
 
 import oracle
 from v4ray_hip import _abi
-from v4ray_hip import (Dielectric, Lambertian, Metal, PerspectiveCameraParam, Renderer, RendererParam, Scene,
-                       SolidColor, Sphere, scenes)
+from v4ray_hip import (ConstantMedium, Cuboid, Dielectric, DiffuseLight, Isotropic, Lambertian, Metal, PerspectiveCameraParam,
+                       Renderer, RendererParam, Scene, SolidColor, Sphere, Triangle, XYRect, YZRect, ZXRect, scenes)
 
 pytestmark = pytest.mark.gpu
 MISS = 0xFFFFFFFF
@@ -130,6 +130,73 @@ def test_constant_medium_free_path_on_device():
     img_d, _ = r.read_accumulator()
     img_o, _ = oracle.render(r.desc, 8, seed=r.seed)
     assert abs(img_d.mean() - img_o.mean()) <= 0.01 * abs(img_o.mean()) + 1e-6
+    r.close()
+
+
+def random_scene(seed, n_shapes):
+    """Spheres, rects, triangles, cuboids and fog volumes of random size and place, half of them under a random
+    rotation + non-uniform scale + translation; a few of them lights."""
+    rng = np.random.default_rng(seed)
+    scene = Scene((0.6, 0.7, 0.9))
+    mats = [Lambertian(SolidColor((0.7, 0.6, 0.5))), Metal((0.8, 0.8, 0.8), 0.2), Dielectric(1.5)]
+
+    def rot(rng):
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        return (q * rng.uniform(0.5, 2.0, size=3)).astype(np.float32)
+
+    for k in range(n_shapes):
+        c = rng.uniform(-10, 10, size=3)
+        kind = rng.integers(0, 6)
+        if kind == 0:
+            shape = Sphere(tuple(c), float(rng.uniform(0.2, 2.0)))
+        elif kind == 1:
+            a, b = np.sort(rng.uniform(-3, 3, size=2)) + c[0], np.sort(rng.uniform(-3, 3, size=2)) + c[1]
+            shape = [XYRect, YZRect, ZXRect][rng.integers(0, 3)](float(a[0]), float(a[1] + 0.1), float(b[0]), float(b[1] + 0.1),
+                                                                  float(c[2]), bool(rng.integers(0, 2)))
+        elif kind == 2:
+            v = c + rng.uniform(-2, 2, size=(3, 3))
+            shape = Triangle([tuple(x) for x in v])
+        elif kind == 3:
+            shape = Cuboid(tuple(c), tuple(c + rng.uniform(0.3, 3, size=3)))
+        elif kind == 4:
+            shape = ConstantMedium(Sphere(tuple(c), float(rng.uniform(0.5, 2.5))), float(rng.uniform(0.2, 3.0)))
+        else:
+            shape = ConstantMedium(Cuboid(tuple(c), tuple(c + rng.uniform(0.5, 3, size=3))), float(rng.uniform(0.2, 3.0)))
+        if rng.random() < 0.5:
+            shape = shape.with_transform(rot(rng), rng.uniform(-3, 3, size=3))
+        if kind >= 4:
+            mat = Isotropic(SolidColor((0.9, 0.9, 0.9)))
+        elif kind in (0, 1) and rng.random() < 0.15:
+            mat = DiffuseLight(SolidColor((4, 4, 4)))
+        else:
+            mat = mats[rng.integers(0, 3)]
+        scene.add(shape, mat)
+    return scene
+
+
+@pytest.mark.parametrize("seed,n_shapes", [(1, 3), (2, 40), (3, 400), (4, 2000)])
+def test_random_scenes_match_oracle(seed, n_shapes):
+    """Random mixed scenes (every primitive kind, transforms, media) against the oracle: random rays through the
+    scene's box, and a few rendered passes."""
+    scene = random_scene(seed, n_shapes)
+    r = Renderer(RendererParam(96, 64, max_depth=12), PerspectiveCameraParam((0, 0, -30), (0, 0, 0), 50.0), scene)
+    rng = np.random.default_rng(100 + seed)
+    n = 20000
+    o = rng.uniform(-14, 14, size=(n, 3)).astype(np.float32)
+    v = rng.normal(size=(n, 3)).astype(np.float32)
+    v = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+    prim_d, t_d = r.trace_rays(o, v, seed=seed)
+    prim_o, t_o = oracle.trace_rays(r.desc, o, v, seed=seed)
+    same = prim_d == prim_o
+    hit = same & (prim_o != MISS)
+    rel = np.abs(t_d[hit] - t_o[hit]) / np.abs(t_o[hit])
+    assert same.mean() >= 0.999, same.mean()
+    assert np.quantile(rel, 0.999) <= 1e-5
+    r.render_passes(4)
+    img_d, _ = r.read_accumulator()
+    img_o, _ = oracle.render(r.desc, 4, seed=r.seed)
+    assert np.isnan(img_d).sum() == np.isnan(img_o).sum()
+    assert abs(np.nanmean(img_d) - np.nanmean(img_o)) <= 0.02 * abs(np.nanmean(img_o)) + 1e-6
     r.close()
 
 
