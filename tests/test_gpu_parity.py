@@ -4,8 +4,11 @@ import pytest
 
 import oracle
 from v4ray_hip import _abi
-from v4ray_hip import (ConstantMedium, Cuboid, Dielectric, DiffuseLight, Isotropic, Lambertian, Metal, PerspectiveCameraParam,
-                       Renderer, RendererParam, Scene, SolidColor, Sphere, Triangle, XYRect, YZRect, ZXRect, scenes)
+import os
+
+from v4ray_hip import (Checker, ConstantMedium, Cuboid, Dielectric, DiffuseLight, ImageTexture, Isotropic, Lambertian, Metal, Noise,
+                       PerspectiveCameraParam, Renderer, RendererParam, Scene, SolidColor, Sphere, Triangle, XYRect, YZRect, ZXRect,
+                       scenes)
 
 pytestmark = pytest.mark.gpu
 MISS = 0xFFFFFFFF
@@ -138,7 +141,10 @@ def random_scene(seed, n_shapes):
     rotation + non-uniform scale + translation; a few of them lights."""
     rng = np.random.default_rng(seed)
     scene = Scene((0.6, 0.7, 0.9))
-    mats = [Lambertian(SolidColor((0.7, 0.6, 0.5))), Metal((0.8, 0.8, 0.8), 0.2), Dielectric(1.5)]
+    mats = [Lambertian(SolidColor((0.7, 0.6, 0.5))), Metal((0.8, 0.8, 0.8), 0.2), Dielectric(1.5),
+            Lambertian(Checker(SolidColor((0.2, 0.3, 0.1)), SolidColor((0.9, 0.9, 0.9)), 3.0)),
+            Lambertian(Noise(2.0, 5)), Lambertian(ImageTexture(os.path.join(scenes.ASSETS, "earthmap.jpg"))),
+            Lambertian(Checker(Noise(1.0, 3), Checker(SolidColor((1, 0, 0)), SolidColor((0, 0, 1)), 7.0), 1.5))]
 
     def rot(rng):
         q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
@@ -164,13 +170,15 @@ def random_scene(seed, n_shapes):
             shape = ConstantMedium(Cuboid(tuple(c), tuple(c + rng.uniform(0.5, 3, size=3))), float(rng.uniform(0.2, 3.0)))
         if rng.random() < 0.5:
             shape = shape.with_transform(rot(rng), rng.uniform(-3, 3, size=3))
+        important = False
         if kind >= 4:
             mat = Isotropic(SolidColor((0.9, 0.9, 0.9)))
-        elif kind in (0, 1) and rng.random() < 0.15:
+        elif kind in (0, 1, 2) and rng.random() < 0.15:
             mat = DiffuseLight(SolidColor((4, 4, 4)))
+            important = bool(rng.integers(0, 2))  # half of the lights are sampled directly (mixture pdf)
         else:
-            mat = mats[rng.integers(0, 3)]
-        scene.add(shape, mat)
+            mat = mats[rng.integers(0, len(mats))]
+        scene.add(shape, mat, important)
     return scene
 
 

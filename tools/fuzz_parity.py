@@ -37,7 +37,12 @@ for seed in range(first, first + count):
     img_d, _ = r.read_accumulator()
     img_o, _ = oracle.render(r.desc, 4, seed=r.seed)
     dm = abs(np.nanmean(img_d) - np.nanmean(img_o)) / (abs(np.nanmean(img_o)) + 1e-9)
-    print(f"seed {seed}: ids {same.mean():.5f}  rel t p99.9 {np.quantile(rel, 0.999):.2e}  image mean diff {dm:.2e}", flush=True)
+    ok = np.isfinite(img_o).all(axis=2) & np.isfinite(img_d).all(axis=2)
+    scale = np.abs(img_o).max(axis=2) + 0.04
+    close = float(((np.abs(img_d - img_o).max(axis=2) / scale)[ok] < 2e-3).mean())
+    print(f"seed {seed}: hit {hit.mean():.3f} image mean {np.nanmean(img_d):.5f} bit-identical pixels {float((img_d == img_o).all(axis=2).mean()):.4f}  ids {same.mean():.5f}  rel t p99.9 {np.quantile(rel, 0.999):.2e}  image mean diff {dm:.2e}  "
+          f"pixels within 2e-3 {close:.4f}  non-finite pixels dev/oracle {int((~np.isfinite(img_d)).any(axis=2).sum())}/"
+          f"{int((~np.isfinite(img_o)).any(axis=2).sum())}", flush=True)
     worst_same, worst_rel, worst_mean = min(worst_same, same.mean()), max(worst_rel, np.quantile(rel, 0.999)), max(worst_mean, dm)
     r.close()
 print(f"worst: ids {worst_same:.5f}, rel t {worst_rel:.2e}, image mean {worst_mean:.2e}")
