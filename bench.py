@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record HIP events around k_trace")
+    ap.add_argument("--split", default="sample", choices=["sample", "tile"],
+                    help="N > 1: rank r renders passes r, r+N, ... of the job (sample) or all passes of its band of rows (tile)")
     ap.add_argument("--no-bunny", action="store_true", help="skip the short bunny-scene (c4) measurement added to the c2 line")
     return ap.parse_args()
 
@@ -140,14 +142,14 @@ def main():
     accum = torch.zeros(height, width, 3, dtype=torch.float32, device=f"cuda:{local_rank}")
     r.bind_accumulator(accum.data_ptr())
 
-    def render(first, stride, n):
-        r.render_passes(n, first_pass=first, pass_stride=stride)
+    def render(first, stride, n, rows=None):
+        r.render_passes(n, first_pass=first, pass_stride=stride, rows=rows)
         if world > 1:
             r.synchronize()  # the renderer runs on its own stream; the collective runs on torch's
 
     def step():
         # rank r: passes r, r+N, ... of an (N * spp)-pass job, then one RCCL reduce of the accumulators
-        render_split(render, accum, spp * world, dst=0)
+        render_split(render, accum, spp * world, dst=0, split=args.split)
 
     def fence():
         r.synchronize()
@@ -230,7 +232,8 @@ def main():
                 "c5": "zy_scene.json (noise/image-textured spheres in a Cornell box)"}[args.workload],
                 "width": width, "height": height, "spp_per_gpu_per_step": spp, "max_depth": scene.renderer_param.max_depth,
                 "paths_per_step": npix * spp * world,
-                "split": "sample-range (pass p on rank p mod N) + RCCL reduce" if world > 1 else "single GPU"},
+                "split": ("single GPU" if world == 1 else "sample-range (pass p on rank p mod N) + RCCL reduce" if args.split == "sample"
+                          else "tile (rank r renders its band of rows) + RCCL reduce")},
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -227,6 +227,15 @@ void v4r_renderer_destroy(v4r_renderer *r);
 int v4r_render(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_t pass_stride,
                uint32_t n_passes);
 
+/* The same for the band of image rows [row0, row0 + n_rows) only (row 0 = top): the tile split of a
+ * multi-GPU job, where every GPU renders all passes of its own band and the accumulators (zero
+ * outside the band) are summed.  Pixels draw the random streams of their position in the whole
+ * image, so bands rendered separately add up to exactly the image v4r_render produces.  The pass
+ * count of the accumulator advances only when the band is the whole image.  No counterpart in the
+ * reference, whose passes are always full images (src/renderer.rs:321-332). */
+int v4r_render_rows(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_t pass_stride, uint32_t n_passes, uint32_t row0,
+                    uint32_t n_rows);
+
 /* Use caller-owned device memory (H*W*3 floats, e.g. a framework tensor that a collective will
  * reduce) as the accumulator from now on; NULL restores the renderer's own buffer.  The buffer is
  * not cleared.  No counterpart in the reference (its accumulator is the RwLock'd Vec of

@@ -216,7 +216,9 @@ V4R_DEV uint32_t class_base(const Queues &Q, uint32_t seg, int cls) {
 // Arguments of the first segment's launch, which generates the camera rays itself (PRIMARY).
 struct PrimaryArgs {
     uint32_t seed_lo, seed_hi, first_pass, pass_stride, n_paths;
-    RayOrder order;
+    uint32_t npix;          // pixels of the band of rows being rendered (the whole image for v4r_render)
+    uint32_t pixel_offset;  // index of the band's first pixel in the image
+    RayOrder order;         // over the band
 };
 // A segment is traced by up to two launches.  In the first, a wave that is down to `give_up_lanes`
 // traversing lanes gives those rays up (their indices go to Q.given_up, through the same chunk-level
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(BLOCK, V4R_TRACE_MIN_WAVES) void k_trace(SceneDev S
     SegCtr *ctr = Q.ctr + seg;
     const uint32_t n_in = second ? ctr->given_up : (PRIMARY ? A.n_paths : rays_in(Q, seg));
     float4 *const *rq = Q.ray[seg & 1u];
-    const uint32_t npix = S.width * S.height;
+    const uint32_t npix = A.npix;  // PRIMARY only
     TraceCounters cnt;
     uint32_t n_traced = 0;
     bool started = false;
@@ -273,10 +275,10 @@ __global__ __launch_bounds__(BLOCK, V4R_TRACE_MIN_WAVES) void k_trace(SceneDev S
                 if (PRIMARY) {
                     // Renderer::sample + Camera::get_ray for queue entry ii (see ray_order); the ray record is
                     // written further down, and only if the ray hits something: a miss ends the path here
-                    ray_order(A.order, S.width, npix, ii, pass_in_batch, pixel);
+                    ray_order(A.order, S.width, npix, ii, pass_in_batch, pixel);  // pixel: within the band
                     uint32_t k0, k1;
-                    path_key(A.seed_lo, A.seed_hi, A.first_pass + pass_in_batch * A.pass_stride, pixel, k0, k1);
-                    camera_ray(S, pixel, segment_key(k0, k1, 0u), false, o, d);
+                    path_key(A.seed_lo, A.seed_hi, A.first_pass + pass_in_batch * A.pass_stride, pixel + A.pixel_offset, k0, k1);
+                    camera_ray(S, pixel + A.pixel_offset, segment_key(k0, k1, 0u), false, o, d);
                 } else {
                     float4 a = rq[0][ii];
                     float2 b = *reinterpret_cast<const float2 *>(&rq[1][ii]);
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(BLOCK, V4R_TRACE_MIN_WAVES) void k_trace(SceneDev S
                 auto key = [&]() {
                     uint32_t k0, k1;
                     if (PRIMARY) {
-                        path_key(A.seed_lo, A.seed_hi, A.first_pass + pass_in_batch * A.pass_stride, pixel, k0, k1);
+                        path_key(A.seed_lo, A.seed_hi, A.first_pass + pass_in_batch * A.pass_stride, pixel + A.pixel_offset, k0, k1);
                     } else {
                         float4 c = rq[2][ii];
                         k0 = __float_as_uint(c.z);
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(BLOCK, V4R_TRACE_MIN_WAVES) void k_trace(SceneDev S
                             p.d = d;
                             p.thr = v3(1, 1, 1);
                             p.slot = pass_in_batch * npix + pixel;
-                            path_key(A.seed_lo, A.seed_hi, A.first_pass + pass_in_batch * A.pass_stride, pixel, p.k0, p.k1);
+                            path_key(A.seed_lo, A.seed_hi, A.first_pass + pass_in_batch * A.pass_stride, pixel + A.pixel_offset, p.k0, p.k1);
                             store_ray(rq, i, p);
                         }
                     } else if (PRIMARY) {  // renderer.rs:184: a miss takes the background colour
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(BLOCK, V4R_TRACE_MIN_WAVES) void k_trace(SceneDev S
             atomicAdd(&Q.stats[6], (unsigned long long)cnt.wave_steps);
             atomicAdd(&Q.stats[7], (unsigned long long)cnt.wave_leaves);
         }
-        if (PRIMARY && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&Q.stats[3], (unsigned long long)A.n_paths);
+        if (PRIMARY && !SECOND && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&Q.stats[3], (unsigned long long)A.n_paths);
     }
 }
 
@@ -1242,8 +1244,10 @@ void launch_shade(v4r_renderer *r, Pipe &pipe, uint32_t seg) {
     else hipLaunchKernelGGL((k_shade<CLS, false>), dim3(r->grid_shade), dim3(BLOCK), 0, pipe.stream, r->S, pipe.Q, seg);
 }
 
-int run_batch(v4r_renderer *r, Pipe &pipe, uint64_t seed, uint32_t first_pass, uint32_t pass_stride, uint32_t n_batch_passes) {
-    uint32_t n_paths = n_batch_passes * r->npix;
+int run_batch(v4r_renderer *r, Pipe &pipe, uint64_t seed, uint32_t first_pass, uint32_t pass_stride, uint32_t n_batch_passes, uint32_t row0,
+              uint32_t n_rows) {
+    const uint32_t band_pix = n_rows * r->S.width, band_offset = row0 * r->S.width;
+    uint32_t n_paths = n_batch_passes * band_pix;
     HIP_TRY(hipMemsetAsync(pipe.Q.ctr, 0, r->ctr_bytes, pipe.stream));
     RayOrder order;
     {
@@ -1255,11 +1259,11 @@ int run_batch(v4r_renderer *r, Pipe &pipe, uint64_t seed, uint32_t first_pass, u
         order.th_log = (6u - lp) / 2u;
         order.tiles_x = r->S.width >> order.tw_log;
         order.tiled_w = order.tiles_x << order.tw_log;
-        order.tiled_h = (r->S.height >> order.th_log) << order.th_log;
+        order.tiled_h = (n_rows >> order.th_log) << order.th_log;
         order.npix_tiled = order.tiled_w * order.tiled_h;
         order.full_groups = n_batch_passes >> lp;
     }
-    PrimaryArgs primary{(uint32_t)seed, (uint32_t)(seed >> 32), first_pass, pass_stride, n_paths, order};
+    PrimaryArgs primary{(uint32_t)seed, (uint32_t)(seed >> 32), first_pass, pass_stride, n_paths, band_pix, band_offset, order};
     for (uint32_t seg = 0; seg < r->S.max_depth; ++seg) {
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         if (r->profiling) {
@@ -1285,7 +1289,8 @@ int run_batch(v4r_renderer *r, Pipe &pipe, uint64_t seed, uint32_t first_pass, u
     }
     // accumulate in batch order: this batch's k_resolve runs after the previous batch's
     if (r->last_resolve && r->last_resolve != pipe.done) HIP_TRY(hipStreamWaitEvent(pipe.stream, r->last_resolve, 0));
-    hipLaunchKernelGGL(k_resolve, dim3(r->grid_stream), dim3(BLOCK), 0, pipe.stream, pipe.Q, r->accum, r->npix, n_batch_passes);
+    hipLaunchKernelGGL(k_resolve, dim3(r->grid_stream), dim3(BLOCK), 0, pipe.stream, pipe.Q, r->accum + 3 * (size_t)band_offset, band_pix,
+                       n_batch_passes);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(pipe.done, pipe.stream));
     r->last_resolve = pipe.done;
@@ -1355,15 +1360,21 @@ void v4r_renderer_destroy(v4r_renderer *r) {
     delete r;
 }
 
-int v4r_render(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_t pass_stride, uint32_t n_passes) {
+int v4r_render_rows(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_t pass_stride, uint32_t n_passes, uint32_t row0,
+                    uint32_t n_rows) {
     if (!r) return set_error(V4R_E_INVALID, "NULL renderer");
+    if (n_rows == 0 || row0 >= r->S.height || n_rows > r->S.height - row0) return set_error(V4R_E_INVALID, "row band outside the image");
     if (pass_stride == 0) pass_stride = 1;
     HIP_TRY(hipSetDevice(r->device));
     if (int rc = fork_pipes(r)) return rc;
+    const uint32_t band_pix = n_rows * r->S.width;
+    // passes per batch for this band: the same number of path slots as a full-image batch
+    uint32_t batch = (uint32_t)std::min<uint64_t>((uint64_t)r->batch_passes * r->npix / band_pix, 4096u);
+    if (batch >= 16u) batch &= ~15u;
+    batch = std::max(1u, batch);
     // A job of at most half a batch is cut into one piece per pipeline so that the pieces overlap (measured:
     // +8-10 % for 16-pass 1080p jobs; larger jobs are better off with few large batches).
-    uint32_t batch = r->batch_passes;
-    if (n_passes <= r->batch_passes / 2u) {
+    if (n_passes <= batch / 2u) {
         uint32_t share = (n_passes + (uint32_t)r->pipes.size() - 1u) / (uint32_t)r->pipes.size();
         if (share >= 16u) share &= ~15u;
         batch = std::max(1u, share);
@@ -1373,13 +1384,18 @@ int v4r_render(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_t pas
         uint32_t nb = std::min(batch, n_passes - done);
         Pipe &pipe = r->pipes[r->next_pipe];
         r->next_pipe = (r->next_pipe + 1) % (uint32_t)r->pipes.size();
-        if (int rc = ensure_pipe(r, pipe, (size_t)nb * r->npix)) return rc;
-        if (int rc = run_batch(r, pipe, seed, first_pass + done * pass_stride, pass_stride, nb)) return rc;
+        if (int rc = ensure_pipe(r, pipe, (size_t)nb * band_pix)) return rc;
+        if (int rc = run_batch(r, pipe, seed, first_pass + done * pass_stride, pass_stride, nb, row0, n_rows)) return rc;
         done += nb;
     }
     if (int rc = join_pipes(r)) return rc;
-    r->n_passes += n_passes;
+    if (n_rows == r->S.height) r->n_passes += n_passes;
     return V4R_OK;
+}
+
+int v4r_render(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_t pass_stride, uint32_t n_passes) {
+    if (!r) return set_error(V4R_E_INVALID, "NULL renderer");
+    return v4r_render_rows(r, seed, first_pass, pass_stride, n_passes, 0, r->S.height);
 }
 
 int v4r_accum_bind(v4r_renderer *r, float *device_hwc) {

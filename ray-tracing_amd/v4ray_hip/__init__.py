@@ -524,9 +524,16 @@ class Renderer:
         return await loop.run_in_executor(None, self.render_pass)
 
     # -- device-resident accumulation --
-    def render_passes(self, n_passes: int, first_pass: int = 0, pass_stride: int = 1, seed: Optional[int] = None) -> None:
-        check_dev(device_lib().v4r_render(self._h, self.seed if seed is None else int(seed), int(first_pass),
-                                          int(pass_stride), int(n_passes)))
+    def render_passes(self, n_passes: int, first_pass: int = 0, pass_stride: int = 1, seed: Optional[int] = None,
+                      rows: Optional[Tuple[int, int]] = None) -> None:
+        """Queue passes first_pass, first_pass + pass_stride, ... (n_passes of them); rows=(row0, n_rows) restricts
+        them to a band of image rows (tile split of a multi-GPU job)."""
+        seed = self.seed if seed is None else int(seed)
+        if rows is None:
+            check_dev(device_lib().v4r_render(self._h, seed, int(first_pass), int(pass_stride), int(n_passes)))
+        else:
+            check_dev(device_lib().v4r_render_rows(self._h, seed, int(first_pass), int(pass_stride), int(n_passes),
+                                                   int(rows[0]), int(rows[1])))
 
     def clear(self) -> None:
         check_dev(device_lib().v4r_accum_clear(self._h))

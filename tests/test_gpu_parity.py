@@ -314,6 +314,23 @@ def test_second_trace_launch_changes_nothing(name, monkeypatch):
         r2.close()
 
 
+def test_row_bands_add_up_to_the_full_image():
+    """Tile split: bands of rows rendered separately (any heights, any order) are exactly the rows of the
+    full-image render, because a pixel's random streams are keyed by its position in the whole image."""
+    scene, r = make("c3")
+    r.render_passes(5)
+    whole, _ = r.read_accumulator()
+    r.clear()
+    h = r.height
+    for row0, n_rows in ((h - 7, 7), (0, 1), (1, 63), (64, h - 71)):
+        r.render_passes(5, rows=(row0, n_rows))
+    bands, n = r.read_accumulator()
+    assert np.array_equal(bands, whole) and n == 0      # partial images do not advance the pass count
+    with pytest.raises(Exception, match="band"):
+        r.render_passes(1, rows=(h - 1, 2))
+    r.close()
+
+
 def test_sample_split_over_ranks_matches_single_rank():
     """Rank r of N renders passes r, r+N, ...: the per-rank sums add up to the single-rank image
     (to fp32 reassociation) because pass p draws the same random streams wherever it runs."""
