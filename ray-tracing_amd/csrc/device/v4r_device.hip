@@ -373,7 +373,8 @@ __global__ __launch_bounds__(BLOCK, V4R_TRACE_MIN_WAVES) void k_trace(SceneDev S
 // Material::emitted + Material::scatter + the pdf branch of ray_color (renderer.rs:218-263) for one
 // material class, then `colors += coef * child` carried forward as the path throughput
 // (renderer.rs:299-318).
-template <int CLS, bool COUNT>
+// NOISE: some texture of the class's materials is (or contains) a Perlin noise texture.
+template <int CLS, bool COUNT, bool NOISE>
 __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, Queues Q, uint32_t seg) {
     SegCtr *ctr = Q.ctr + seg;
     const uint32_t n_in = ctr->hit_count[CLS];
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, Queues Q, uint32_t 
 
         if (CLS == CLS_LIGHT) {  // material/diffuse_light.rs:19-22; scatter() is the default None
             HitD h = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, false);
-            V3 e = texture_value(
+            V3 e = texture_value<NOISE>(
                 S, m[1], h.p,
                 [&](float &u, float &v) {
                     HitD hu = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, true);
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, Queues Q, uint32_t 
         HitD h;
         if (CLS == CLS_LAMBERT || CLS == CLS_LAMBERT_NOISE) {  // material/lambertian.rs:36-46
             h = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, false);
-            V3 attenuation = texture_value(
+            V3 attenuation = texture_value<NOISE>(
                 S, m[1], h.p,
                 [&](float &u, float &v) {
                     HitD hu = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, true);
@@ -472,7 +473,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, Queues Q, uint32_t 
             float sn, cs;
             sincosf(theta, &sn, &cs);
             dir = v3(cs * xy, sn * xy, z);
-            coef = texture_value(
+            coef = texture_value<NOISE>(
                 S, m[1], h.p,
                 [&](float &u, float &v) {
                     HitD hu = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, true);
@@ -630,6 +631,7 @@ struct v4r_renderer {
     uint64_t trace_launches = 0;
     bool has_class[CLS_COUNT] = {false, false, false, false, false, false};
     bool has_media = false;  // selects the kernels that carry the constant-medium test
+    bool class_noise[CLS_COUNT] = {false, false, false, false, false, false};  // a material of the class uses a noise texture
     uint32_t give_up_lanes = 0, give_up_segments = 0;  // see k_trace
     size_t ctr_bytes = 0;
     uint32_t max_depth = 0, spill_depth = 0;
@@ -1110,9 +1112,12 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     if (int rc = r->upload(&S.prims, (const float4 *)d->prims, (size_t)d->n_prims * 3)) return rc;
     std::vector<uint32_t> info(d->n_prims);
     for (uint32_t i = 0; i < d->n_prims; ++i) {
-        uint32_t cls = class_of(d, d->materials[d->prim_material[i]]);
+        const v4r_material &mat = d->materials[d->prim_material[i]];
+        uint32_t cls = class_of(d, mat);
         info[i] = d->prim_material[i] | (cls << 24);
         r->has_class[cls] = true;
+        bool textured = mat.kind == V4R_MAT_LAMBERTIAN || mat.kind == V4R_MAT_DIFFUSE_LIGHT || mat.kind == V4R_MAT_ISOTROPIC;
+        if (textured && has_noise(d, mat.tex)) r->class_noise[cls] = true;
     }
     if (int rc = r->upload(&S.prim_info, info.data(), info.size())) return rc;
     if (int rc = r->upload(&S.xforms, (const float *)d->xforms, (size_t)d->n_xforms * 24)) return rc;
@@ -1240,8 +1245,16 @@ void launch_trace(v4r_renderer *r, Pipe &pipe, uint32_t seg, const PrimaryArgs &
 template <int CLS>
 void launch_shade(v4r_renderer *r, Pipe &pipe, uint32_t seg) {
     if (!r->has_class[CLS]) return;
-    if (r->counting) hipLaunchKernelGGL((k_shade<CLS, true>), dim3(r->grid_shade), dim3(BLOCK), 0, pipe.stream, r->S, pipe.Q, seg);
-    else hipLaunchKernelGGL((k_shade<CLS, false>), dim3(r->grid_shade), dim3(BLOCK), 0, pipe.stream, r->S, pipe.Q, seg);
+    dim3 grid(r->grid_shade), block(BLOCK);
+    // Lambertian materials are classed by noise already; metal and dielectric have no texture
+    constexpr bool maybe_noise = CLS == CLS_LIGHT || CLS == CLS_ISOTROPIC;
+    if (CLS == CLS_LAMBERT_NOISE || (maybe_noise && r->class_noise[CLS])) {
+        if (r->counting) hipLaunchKernelGGL((k_shade<CLS, true, true>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg);
+        else hipLaunchKernelGGL((k_shade<CLS, false, true>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg);
+    } else {
+        if (r->counting) hipLaunchKernelGGL((k_shade<CLS, true, false>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg);
+        else hipLaunchKernelGGL((k_shade<CLS, false, false>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg);
+    }
 }
 
 int run_batch(v4r_renderer *r, Pipe &pipe, uint64_t seed, uint32_t first_pass, uint32_t pass_stride, uint32_t n_batch_passes, uint32_t row0,

@@ -530,7 +530,9 @@ V4R_DEV float perlin_noise(const float4 *vec, const uint8_t *perm, V3 p) {
 }
 
 // Texture::value for the four texture kinds; `uvf` computes (u,v) on demand.
-template <class UV>
+// NOISE = false compiles the Perlin branch out, for material classes whose texture trees hold no noise
+// texture (the eight unrolled lattice terms cost ~25 registers).
+template <bool NOISE, class UV>
 V4R_DEV V3 texture_value(const SceneDev &S, uint32_t tex, V3 p, UV uvf, uint32_t &texel_fetches) {
     for (int guard = 0; guard < 64; ++guard) {
         const uint32_t *t = S.textures + 8 * (size_t)tex;
@@ -557,7 +559,7 @@ V4R_DEV V3 texture_value(const SceneDev &S, uint32_t tex, V3 p, UV uvf, uint32_t
             texel_fetches++;
             return v3((float)(px & 255u) / 255.0f, (float)((px >> 8) & 255u) / 255.0f, (float)((px >> 16) & 255u) / 255.0f);
         }
-        if (kind == V4R_TEX_NOISE) {  // texture/noise.rs:91-107,165-170
+        if (NOISE && kind == V4R_TEX_NOISE) {  // texture/noise.rs:91-107,165-170
             float scale = __uint_as_float(t[4]);
             uint32_t depth = t[6];
             const float4 *vec = S.perlin_vec + 256 * (size_t)t[5];
