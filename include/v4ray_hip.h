@@ -242,6 +242,14 @@ int v4r_render_rows(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_
  * src/renderer.rs:336-340). */
 int v4r_accum_bind(v4r_renderer *r, float *device_hwc);
 
+/* Sum the accumulators of all ranks of an RCCL communicator onto rank `root`, in place, on the
+ * renderer's stream (after the passes queued so far): one ncclReduce(sum, fp32, H*W*3) over xGMI, the
+ * only exchange step of a multi-GPU job.  `rccl_comm` is the caller's ncclComm_t; the library does not
+ * link RCCL: it uses the ncclReduce already loaded in the process, else librccl.so.1.  Replaces the
+ * RwLock'd sum of RenderResult::add across the reference's concurrent passes (src/main.rs:56-63,
+ * src/renderer.rs:355-368). */
+int v4r_reduce(v4r_renderer *r, void *rccl_comm, int root);
+
 /* Zero the accumulator and the pass count. Replaces RenderResult::new (src/renderer.rs:343-354). */
 int v4r_accum_clear(v4r_renderer *r);
 

@@ -16,6 +16,7 @@
 // queue entries is one contiguous 1 KiB transaction per column.  A path's radiance is written
 // exactly once, when it terminates (miss, light, depth exhausted), into a per-path slot; k_resolve
 // adds the slots of a pixel in ascending pass order, which keeps the image bit-reproducible.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -1416,6 +1417,24 @@ int v4r_accum_bind(v4r_renderer *r, float *device_hwc) {
     HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(hipStreamSynchronize(r->stream));
     r->accum = device_hwc ? device_hwc : r->accum_own;
+    return V4R_OK;
+}
+
+int v4r_reduce(v4r_renderer *r, void *rccl_comm, int root) {
+    if (!r || !rccl_comm) return set_error(V4R_E_INVALID, "NULL argument");
+    // ncclResult_t ncclReduce(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t)
+    using reduce_fn = int (*)(const void *, void *, size_t, int, int, int, void *, hipStream_t);
+    static reduce_fn reduce = [] {
+        void *sym = dlsym(RTLD_DEFAULT, "ncclReduce");  // the RCCL the caller's communicator came from, if it is loaded globally
+        if (!sym)
+            if (void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL)) sym = dlsym(lib, "ncclReduce");
+        return (reduce_fn)sym;
+    }();
+    if (!reduce) return set_error(V4R_E_UNSUPPORTED, "ncclReduce not found: load RCCL (librccl.so.1) before calling v4r_reduce");
+    HIP_TRY(hipSetDevice(r->device));
+    constexpr int nccl_float32 = 7, nccl_sum = 0;  // rccl.h: ncclFloat32, ncclSum
+    int rc = reduce(r->accum, r->accum, (size_t)r->npix * 3, nccl_float32, nccl_sum, root, rccl_comm, r->stream);
+    if (rc != 0) return set_error(V4R_E_HIP, "ncclReduce failed with ncclResult_t " + std::to_string(rc));
     return V4R_OK;
 }
 

@@ -331,6 +331,37 @@ def test_row_bands_add_up_to_the_full_image():
     r.close()
 
 
+def test_reduce_through_an_rccl_communicator():
+    """v4r_reduce on a one-rank RCCL communicator made by the caller (C hosts do the same with N ranks): the
+    call is accepted, runs on the renderer's stream and leaves the single rank's sums as they are."""
+    import ctypes as C
+    from v4ray_hip import _abi
+    try:
+        rccl = C.CDLL("librccl.so.1", mode=C.RTLD_GLOBAL)
+    except OSError:
+        rccl = C.CDLL("/opt/rocm/lib/librccl.so.1", mode=C.RTLD_GLOBAL)
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid, comm = UniqueId(), C.c_void_p()
+    rccl.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    scene, r = make("c3")
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    r.render_passes(3)
+    before, _ = r.read_accumulator()
+    lib = _abi.device_lib()
+    assert lib.v4r_reduce(r._h, comm, 0) == 0, lib.v4r_last_error()
+    after, n = r.read_accumulator()
+    assert n == 3 and np.array_equal(before, after)
+    assert lib.v4r_reduce(r._h, None, 0) == -1
+    rccl.ncclCommDestroy(comm)
+    r.close()
+
+
 def test_sample_split_over_ranks_matches_single_rank():
     """Rank r of N renders passes r, r+N, ...: the per-rank sums add up to the single-rank image
     (to fp32 reassociation) because pass p draws the same random streams wherever it runs."""
