@@ -52,5 +52,11 @@ def test_cli_renders_reference_scene_and_resumes(tmp_path):
         assert "Resumed at iter 4" in out and "Iter 8 saved" in out
         assert load_checkpoint(ck)[1] == 8
         assert np.array_equal(read_bmp(two), img)
+        # two renderers from one process (here both on GPU 0): passes split k, k+2, ..., sums merged on the host
+        multi = str(tmp_path / "multi.bmp")
+        out = run(["-i", scene_file, "-o", multi, "--spp", "8", "--batch", "4", "--devices", "0,0"], scenes.ASSETS)
+        assert "Iter 8 saved" in out
+        diff = np.abs(read_bmp(multi).astype(int) - img.astype(int))
+        assert diff.max() <= 1 and (diff > 0).mean() < 0.01      # fp32 sums in another order, then 8-bit tonemap
     finally:
         os.remove(scene_file)
