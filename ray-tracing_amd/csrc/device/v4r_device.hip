@@ -396,14 +396,15 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, Queues Q, uint32_t 
         float4 dcol = Q.hitd[src];
         float t = dcol.x;
         uint32_t prim = __float_as_uint(dcol.y);
-        const uint32_t *m = S.materials + 8 * (size_t)(S.prim_info[prim] & 0xFFFFFFu);
+        // the material's parameters (metal, dielectric) or the record of its texture (the textured kinds)
+        const uint4 rec0 = S.prim_shade[2 * (size_t)prim], rec1 = S.prim_shade[2 * (size_t)prim + 1];
         uint32_t key = segment_key(p.k0, p.k1, seg);
         if (valid) n_shaded++;
 
         if (CLS == CLS_LIGHT) {  // material/diffuse_light.rs:19-22; scatter() is the default None
             HitD h = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, false);
             V3 e = texture_value<NOISE>(
-                S, m[1], h.p,
+                S, rec0, rec1, h.p,
                 [&](float &u, float &v) {
                     HitD hu = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, true);
                     u = hu.u;
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, Queues Q, uint32_t 
         if (CLS == CLS_LAMBERT || CLS == CLS_LAMBERT_NOISE) {  // material/lambertian.rs:36-46
             h = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, false);
             V3 attenuation = texture_value<NOISE>(
-                S, m[1], h.p,
+                S, rec0, rec1, h.p,
                 [&](float &u, float &v) {
                     HitD hu = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, true);
                     u = hu.u;
@@ -443,7 +444,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, Queues Q, uint32_t 
         } else if (CLS == CLS_METAL) {  // material/metal.rs:31-46, random_in_unit_sphere random.rs:53-65
             h = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, false);
             V3 reflected = reflect(p.d, h.normal);
-            float fuzz = __uint_as_float(m[5]);
+            float fuzz = __uint_as_float(rec1.y);
             V3 ball = v3(0, 0, 0);
             if (fuzz != 0.0f) {
                 float theta = TWO_PI * draw(key, DIM_SCATTER + 0);
@@ -455,10 +456,10 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, Queues Q, uint32_t 
                 ball = v3(r * sin_phi * cs, r * sin_phi * sn, r * cos_phi);
             }
             dir = normalize(reflected + ball * fuzz);
-            coef = v3(__uint_as_float(m[2]), __uint_as_float(m[3]), __uint_as_float(m[4]));
+            coef = v3(__uint_as_float(rec0.z), __uint_as_float(rec0.w), __uint_as_float(rec1.x));
         } else if (CLS == CLS_DIELECTRIC) {  // material/dielectric.rs:33-60
             h = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, false);
-            float ir = __uint_as_float(m[6]);
+            float ir = __uint_as_float(rec1.z);
             float ratio = h.front ? 1.0f / ir : ir;
             float cos_theta = -dot(p.d, h.normal);
             float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, Queues Q, uint32_t 
             sincosf(theta, &sn, &cs);
             dir = v3(cs * xy, sn * xy, z);
             coef = texture_value<NOISE>(
-                S, m[1], h.p,
+                S, rec0, rec1, h.p,
                 [&](float &u, float &v) {
                     HitD hu = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, true);
                     u = hu.u;
@@ -1121,6 +1122,16 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
         if (textured && has_noise(d, mat.tex)) r->class_noise[cls] = true;
     }
     if (int rc = r->upload(&S.prim_info, info.data(), info.size())) return rc;
+    {
+        std::vector<uint4> shade((size_t)d->n_prims * 2);
+        for (uint32_t i = 0; i < d->n_prims; ++i) {
+            const v4r_material &mat = d->materials[d->prim_material[i]];
+            bool textured = mat.kind == V4R_MAT_LAMBERTIAN || mat.kind == V4R_MAT_DIFFUSE_LIGHT || mat.kind == V4R_MAT_ISOTROPIC;
+            static_assert(sizeof(v4r_material) == 32 && sizeof(v4r_texture) == 32, "shade records are 32 bytes");
+            std::memcpy(&shade[2 * (size_t)i], textured ? (const void *)&d->textures[mat.tex] : (const void *)&mat, 32);
+        }
+        if (int rc = r->upload(&S.prim_shade, shade.data(), shade.size())) return rc;
+    }
     if (int rc = r->upload(&S.xforms, (const float *)d->xforms, (size_t)d->n_xforms * 24)) return rc;
     if (int rc = r->upload(&S.tri, (const float4 *)d->tri_shading, (size_t)d->n_tri_shading * 4)) return rc;
     if (int rc = r->upload(&S.media, (const uint4 *)d->media, (size_t)d->n_media)) return rc;

@@ -24,6 +24,7 @@ constexpr uint32_t NO_PRIM = 0xFFFFFFFFu;
 struct SceneDev {
     const float4 *nodes4;        // 8 x float4 per 4-wide node (wide_step)
     const float4 *prims;         // 3 x float4 per primitive (v4r_prim)
+    const uint4 *prim_shade;     // 2 x uint4 per primitive: its material's root texture record (textured materials) or material record
     const uint32_t *prim_info;   // material index | shading class << 24
     const float *xforms;         // 24 floats per transform (v4r_xform)
     const float4 *tri;           // 4 x float4 per triangle (v4r_tri_shading)
@@ -532,17 +533,24 @@ V4R_DEV float perlin_noise(const float4 *vec, const uint8_t *perm, V3 p) {
 // Texture::value for the four texture kinds; `uvf` computes (u,v) on demand.
 // NOISE = false compiles the Perlin branch out, for material classes whose texture trees hold no noise
 // texture (the eight unrolled lattice terms cost ~25 registers).
+// `root` is the 32-byte record of the texture to evaluate, already in registers (the shading kernels
+// get it from the per-primitive table prim_shade, which saves the material -> texture pointer chase);
+// children of checker textures are fetched from S.textures.
 template <bool NOISE, class UV>
-V4R_DEV V3 texture_value(const SceneDev &S, uint32_t tex, V3 p, UV uvf, uint32_t &texel_fetches) {
+V4R_DEV V3 texture_value(const SceneDev &S, uint4 root0, uint4 root1, V3 p, UV uvf, uint32_t &texel_fetches) {
+    uint32_t t[8] = {root0.x, root0.y, root0.z, root0.w, root1.x, root1.y, root1.z, root1.w};
     for (int guard = 0; guard < 64; ++guard) {
-        const uint32_t *t = S.textures + 8 * (size_t)tex;
         uint32_t kind = t[0];
         if (kind == V4R_TEX_SOLID)  // texture/solid_color.rs:25-27
             return v3(__uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3]));
         if (kind == V4R_TEX_CHECKER) {  // texture/checker.rs:31-38
             float dens = __uint_as_float(t[4]);
             float sines = sinf(dens * p.x) * sinf(dens * p.y) * sinf(dens * p.z);
-            tex = sines > 0.0f ? t[6] : t[5];  // even : odd
+            uint32_t tex = sines > 0.0f ? t[6] : t[5];  // even : odd
+            const uint4 *child = reinterpret_cast<const uint4 *>(S.textures + 8 * (size_t)tex);
+            uint4 c0 = child[0], c1 = child[1];
+            t[0] = c0.x, t[1] = c0.y, t[2] = c0.z, t[3] = c0.w;
+            t[4] = c1.x, t[5] = c1.y, t[6] = c1.z, t[7] = c1.w;
             continue;
         }
         if (kind == V4R_TEX_IMAGE) {  // texture/image.rs:25-73
