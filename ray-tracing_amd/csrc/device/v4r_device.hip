@@ -212,7 +212,7 @@ V4R_DEV uint32_t class_base(const Queues &Q, uint32_t seg, int cls) {
 // scenes and 46 % on the bunny scene, but its extra votes and low-occupancy set-up code made all but
 // the bunny scene 5-20 % slower, so rays are assigned statically.)
 #ifndef V4R_TRACE_MIN_WAVES
-#define V4R_TRACE_MIN_WAVES 1
+#define V4R_TRACE_MIN_WAVES 1  // tuning hook: forcing 6 waves/SIMD (80 VGPRs) spills and is not faster
 #endif
 // Arguments of the first segment's launch, which generates the camera rays itself (PRIMARY).
 struct PrimaryArgs {
@@ -230,10 +230,6 @@ template <bool COUNT, int RAYS_PER_THREAD, bool MEDIA, bool PRIMARY, bool SECOND
 __global__ __launch_bounds__(BLOCK, V4R_TRACE_MIN_WAVES) void k_trace(SceneDev S, Queues Q, uint32_t seg, PrimaryArgs A, uint32_t give_up_lanes) {
     constexpr bool second = SECOND;
     __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
-#ifdef V4R_LDS_PAD
-    __shared__ uint32_t lds_pad[V4R_LDS_PAD / 4];
-    if (seg == 0xFFFFFFFFu) lds_pad[threadIdx.x] = 1, Q.stats[threadIdx.x] = lds_pad[threadIdx.x ^ 1];
-#endif
     __shared__ uint32_t s_base;
     __shared__ uint32_t s_cnt[CLS_COUNT + 1];  // [CLS_COUNT]: rays given up
     __shared__ uint32_t s_where[RAYS_PER_THREAD * BLOCK];  // per ray of the chunk: class << 16 | rank among the chunk's hits of that class
