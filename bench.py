@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-profile", action="store_true", help="do not record HIP events around k_trace")
     ap.add_argument("--split", default="sample", choices=["sample", "tile"],
                     help="N > 1: rank r renders passes r, r+N, ... of the job (sample) or all passes of its band of rows (tile)")
+    ap.add_argument("--c4-subdivide", type=int, default=2, help="midpoint subdivisions of bunny.obj in c4 (2: 79 488 triangles, 0: 4 968)")
     ap.add_argument("--no-bunny", action="store_true", help="skip the short bunny-scene (c4) measurement added to the c2 line")
     return ap.parse_args()
 
@@ -136,7 +137,8 @@ def main():
     spp = args.spp or fspp
     # the bunny's mesh transform is baked into its triangles on the host: the same geometry without a per-test
     # ray transform (tests/test_gpu_parity.py::test_primary_hits_pretransformed_bunny checks ids and t)
-    scene = scenes.load(args.workload, width, height, pretransform_triangles=True)
+    extra = {"subdivide": args.c4_subdivide} if args.workload == "c4" and args.c4_subdivide != 2 else {}
+    scene = scenes.load(args.workload, width, height, pretransform_triangles=True, **extra)
     r = Renderer(scene.renderer_param, scene.camera_param, scene, device=local_rank)
     npix = width * height
     accum = torch.zeros(height, width, 3, dtype=torch.float32, device=f"cuda:{local_rank}")
@@ -228,7 +230,8 @@ def main():
                 "c1": "data/scene.json verbatim (Cornell walls, 4 968-triangle bunny, fog sphere, 4 985 shapes)",
                 "c2": "Book-1 random-spheres scene (484 spheres, Lambertian/metal/dielectric)",
                 "c3": "Cornell box, cosine + light-list mixture sampling",
-                "c4": "bunny.obj subdivided to 79 488 triangles + earth-textured sphere in a Cornell box",
+                "c4": ("bunny.obj subdivided to 79 488 triangles" if args.c4_subdivide == 2 else f"bunny.obj, {args.c4_subdivide} subdivision(s)")
+                      + " + earth-textured sphere in a Cornell box",
                 "c5": "zy_scene.json (noise/image-textured spheres in a Cornell box)"}[args.workload],
                 "width": width, "height": height, "spp_per_gpu_per_step": spp, "max_depth": scene.renderer_param.max_depth,
                 "paths_per_step": npix * spp * world,
