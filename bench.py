@@ -74,7 +74,11 @@ def cpu_baseline(desc, npix, seed):
         t0 = time.perf_counter()
         oracle.render(desc, passes, seed=seed, threads=cores)
         dt = time.perf_counter() - t0
-    return {"value": round(npix * passes / dt / 1e6, 4), "unit": "Mpaths/s", "cores": cores, "kind": "port",
+    # one thread, every 4th pixel of one pass (the rate does not depend on which pixels are sampled)
+    t0 = time.perf_counter()
+    oracle.render(desc, 1, seed=seed, threads=1, pixel_stride=4)
+    one = (npix + 3) // 4 / (time.perf_counter() - t0) / 1e6
+    return {"value": round(npix * passes / dt / 1e6, 4), "unit": "Mpaths/s", "cores": cores, "kind": "port", "value_1_thread": round(one, 4),
             "sample": f"{passes} full-resolution 1-spp pass(es) of the same scene, {cores} threads, "
                       f"reference-order (unordered candidate-set) BVH traversal"}
 
