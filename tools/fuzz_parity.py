@@ -22,8 +22,15 @@ shapes = int(sys.argv[3]) if len(sys.argv) > 3 else 300
 worst_same, worst_rel, worst_mean = 1.0, 0.0, 0.0
 for seed in range(first, first + count):
     scene = random_scene(seed, shapes)
-    r = Renderer(RendererParam(64, 48, max_depth=10), PerspectiveCameraParam((0, 0, -30), (0, 0, 0), 50.0), scene)
     rng = np.random.default_rng(1000 + seed)
+    # random camera: position, field of view, lens aperture / focus, antialiasing on or off, odd image sizes
+    eye = rng.normal(size=3)
+    eye = tuple(float(x) for x in eye / np.linalg.norm(eye) * rng.uniform(5, 40))
+    cam = PerspectiveCameraParam(eye, tuple(float(x) for x in rng.uniform(-3, 3, size=3)), float(rng.uniform(20, 90)),
+                                 aperture=float(rng.choice([0.0, 0.3, 2.0])), focus_dist=float(rng.uniform(5, 30)))
+    param = RendererParam(int(rng.integers(17, 97)), int(rng.integers(9, 71)), max_depth=int(rng.integers(1, 30)),
+                          antialias=bool(rng.integers(0, 2)))
+    r = Renderer(param, cam, scene)
     n = 30000
     o = rng.uniform(-14, 14, size=(n, 3)).astype(np.float32)
     v = rng.normal(size=(n, 3)).astype(np.float32)
