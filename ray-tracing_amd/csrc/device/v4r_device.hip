@@ -214,6 +214,9 @@ V4R_DEV uint32_t class_base(const Queues &Q, uint32_t seg, int cls) {
 #ifndef V4R_TRACE_MIN_WAVES
 #define V4R_TRACE_MIN_WAVES 1  // tuning hook: forcing 6 waves/SIMD (80 VGPRs) spills and is not faster
 #endif
+#ifndef V4R_TRACE_MIN_WAVES_MEDIA
+#define V4R_TRACE_MIN_WAVES_MEDIA 4  // the kernels with the constant-medium code need 133-143 VGPRs unforced (3 waves/SIMD)
+#endif
 // Arguments of the first segment's launch, which generates the camera rays itself (PRIMARY).
 struct PrimaryArgs {
     uint32_t seed_lo, seed_hi, first_pass, pass_stride, n_paths;
@@ -227,7 +230,7 @@ struct PrimaryArgs {
 // segment packed next to each other, starting from the closest hit they had found, and never gives up.
 // (SECOND is a template parameter because the extra index it carries costs the first launch an occupancy step.)
 template <bool COUNT, int RAYS_PER_THREAD, bool MEDIA, bool PRIMARY, bool SECOND>
-__global__ __launch_bounds__(BLOCK, V4R_TRACE_MIN_WAVES) void k_trace(SceneDev S, Queues Q, uint32_t seg, PrimaryArgs A, uint32_t give_up_lanes) {
+__global__ __launch_bounds__(BLOCK, MEDIA ? V4R_TRACE_MIN_WAVES_MEDIA : V4R_TRACE_MIN_WAVES) void k_trace(SceneDev S, Queues Q, uint32_t seg, PrimaryArgs A, uint32_t give_up_lanes) {
     constexpr bool second = SECOND;
     __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
     __shared__ uint32_t s_base;
