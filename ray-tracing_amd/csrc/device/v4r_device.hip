@@ -1396,12 +1396,14 @@ int v4r_render_rows(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_
     uint32_t batch = (uint32_t)std::min<uint64_t>((uint64_t)r->batch_passes * r->npix / band_pix, 4096u);
     if (batch >= 16u) batch &= ~15u;
     batch = std::max(1u, batch);
-    // A job of at most half a batch is cut into one piece per pipeline so that the pieces overlap (measured:
-    // +8-10 % for 16-pass 1080p jobs; larger jobs are better off with few large batches).
-    if (n_passes <= batch / 2u) {
-        uint32_t share = (n_passes + (uint32_t)r->pipes.size() - 1u) / (uint32_t)r->pipes.size();
-        if (share >= 16u) share &= ~15u;
-        batch = std::max(1u, share);
+    // A job of fewer batches than pipelines is cut into one piece per pipeline (multiples of 16 passes, the
+    // camera-ray tile) so that the pieces overlap: measured +12 % for a 32-pass 1080p job and +6 % for 128 passes
+    // of 800x800; jobs of many batches are better off with few large ones.
+    const uint32_t n_pipes = (uint32_t)r->pipes.size();
+    if ((n_passes + batch - 1u) / batch < n_pipes) {
+        uint32_t share = (n_passes + n_pipes - 1u) / n_pipes;
+        if (share >= 16u) share = (share + 15u) & ~15u;
+        batch = std::max(1u, std::min(batch, share));
     }
     uint32_t done = 0;
     while (done < n_passes) {
