@@ -370,10 +370,116 @@ __global__ __launch_bounds__(BLOCK, MEDIA ? V4R_TRACE_MIN_WAVES_MEDIA : V4R_TRAC
     }
 }
 
-// Material::emitted + Material::scatter + the pdf branch of ray_color (renderer.rs:218-263) for one
-// material class, then `colors += coef * child` carried forward as the path throughput
-// (renderer.rs:299-318).
+// Material::emitted + Material::scatter + the pdf branch of ray_color (renderer.rs:218-263) for one hit of
+// material class CLS, then `colors += coef * child` carried forward as the path throughput
+// (renderer.rs:299-318).  `dcol` is the hit as k_trace leaves it: distance, primitive, triangle barycentrics.
+// Returns true with the path's next ray in `q`, or false with the radiance the path ends with in `rad`
+// (it met a light, or its depth budget is spent).
 // NOISE: some texture of the class's materials is (or contains) a Perlin noise texture.
+template <int CLS, bool NOISE>
+V4R_DEV bool shade_hit(const SceneDev &S, const PathState &p, float4 dcol, uint32_t seg, uint32_t &texel_fetches, PathState &q, float4 &rad) {
+    const float t = dcol.x;
+    const uint32_t prim = __float_as_uint(dcol.y);
+    // the material's parameters (metal, dielectric) or the record of its texture (the textured kinds)
+    const uint4 rec0 = S.prim_shade[2 * (size_t)prim], rec1 = S.prim_shade[2 * (size_t)prim + 1];
+    const uint32_t key = segment_key(p.k0, p.k1, seg);
+    if (CLS == CLS_LIGHT) {  // material/diffuse_light.rs:19-22; scatter() is the default None
+        HitD h = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, false);
+        V3 e = texture_value<NOISE>(
+            S, rec0, rec1, h.p,
+            [&](float &u, float &v) {
+                HitD hu = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, true);
+                u = hu.u;
+                v = hu.v;
+            },
+            texel_fetches);
+        if (!h.front) e = v3(0, 0, 0);
+        rad = make_float4(p.thr.x * e.x, p.thr.y * e.y, p.thr.z * e.z, 0.0f);
+        return false;
+    }
+
+    V3 coef, dir;
+    HitD h;
+    if (CLS == CLS_LAMBERT || CLS == CLS_LAMBERT_NOISE) {  // material/lambertian.rs:36-46
+        h = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, false);
+        V3 attenuation = texture_value<NOISE>(
+            S, rec0, rec1, h.p,
+            [&](float &u, float &v) {
+                HitD hu = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, true);
+                u = hu.u;
+                v = hu.v;
+            },
+            texel_fetches);
+        V3 d_cos = cosine_generate(h.normal, draw(key, DIM_SCATTER + 4), draw(key, DIM_SCATTER + 5));
+        if (S.n_lights != 0) {  // renderer.rs:234-244, pdf/mixture.rs:22-32, hittables/group.rs:91-95
+            bool pick_light = draw(key, DIM_SCATTER + 0) < 0.5f;
+            uint32_t li = (uint32_t)(((unsigned long long)draw_u32(key, DIM_SCATTER + 1) * S.n_lights) >> 32);
+            V3 d_light = light_generate(S, S.lights[li], h.p, draw(key, DIM_SCATTER + 2), draw(key, DIM_SCATTER + 3));
+            dir = pick_light ? d_light : d_cos;
+            float pdf_v = cosine_value(h.normal, dir);
+            float mix_v = 0.5f * lights_value(S, h.p, dir) + 0.5f * pdf_v;
+            coef = attenuation * pdf_v / mix_v;
+        } else {  // renderer.rs:245-255
+            dir = d_cos;
+            coef = attenuation;
+        }
+    } else if (CLS == CLS_METAL) {  // material/metal.rs:31-46, random_in_unit_sphere random.rs:53-65
+        h = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, false);
+        V3 reflected = reflect(p.d, h.normal);
+        float fuzz = __uint_as_float(rec1.y);
+        V3 ball = v3(0, 0, 0);
+        if (fuzz != 0.0f) {
+            float theta = TWO_PI * draw(key, DIM_SCATTER + 0);
+            float cos_phi = -1.0f + 2.0f * draw(key, DIM_SCATTER + 1);
+            float r = powf(draw(key, DIM_SCATTER + 2), 1.0f / 3.0f);
+            float sin_phi = sqrtf(1.0f - cos_phi * cos_phi);
+            float sn, cs;
+            sincosf(theta, &sn, &cs);
+            ball = v3(r * sin_phi * cs, r * sin_phi * sn, r * cos_phi);
+        }
+        dir = normalize(reflected + ball * fuzz);
+        coef = v3(__uint_as_float(rec0.z), __uint_as_float(rec0.w), __uint_as_float(rec1.x));
+    } else if (CLS == CLS_DIELECTRIC) {  // material/dielectric.rs:33-60
+        h = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, false);
+        float ir = __uint_as_float(rec1.z);
+        float ratio = h.front ? 1.0f / ir : ir;
+        float cos_theta = -dot(p.d, h.normal);
+        float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+        bool cannot_refract = ratio * sin_theta > 1.0f;
+        cannot_refract = cannot_refract || reflectance(cos_theta, ratio) > draw(key, DIM_SCATTER + 0);
+        dir = cannot_refract ? reflect(p.d, h.normal) : refract(p.d, h.normal, ratio);
+        coef = v3(1, 1, 1);
+    } else {  // CLS_ISOTROPIC: material/isotropic.rs:26-43, random_on_unit_sphere random.rs:41-51
+        h = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, false);
+        float z = -1.0f + 2.0f * draw(key, DIM_SCATTER + 0);
+        float theta = TWO_PI * draw(key, DIM_SCATTER + 1);
+        float xy = sqrtf(1.0f - z * z);
+        float sn, cs;
+        sincosf(theta, &sn, &cs);
+        dir = v3(cs * xy, sn * xy, z);
+        coef = texture_value<NOISE>(
+            S, rec0, rec1, h.p,
+            [&](float &u, float &v) {
+                HitD hu = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, true);
+                u = hu.u;
+                v = hu.v;
+            },
+            texel_fetches);
+    }
+    q.o = h.p;
+    q.d = dir;
+    q.thr = p.thr * coef;
+    q.slot = p.slot;
+    q.k0 = p.k0;
+    q.k1 = p.k1;
+    if (seg + 1u >= S.max_depth) {  // renderer.rs:128-130: the depth budget is spent, the child returns `environment`
+        rad = make_float4(q.thr.x * S.env[0], q.thr.y * S.env[1], q.thr.z * S.env[2], 0.0f);
+        return false;
+    }
+    return true;
+}
+
+// Shading of the hits of one material class of one segment.
 template <int CLS, bool COUNT, bool NOISE>
 __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, Queues Q, uint32_t seg) {
     SegCtr *ctr = Q.ctr + seg;
@@ -381,7 +487,6 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, Queues Q, uint32_t 
     const uint32_t *hq = Q.hit[CLS];
     float4 *const *rq = Q.ray[seg & 1u];  // the rays k_trace just traced; the survivors go to the other queue
     float4 *const *out = Q.ray[(seg + 1u) & 1u];
-    const bool last = seg + 1u >= S.max_depth;
     const uint32_t out_base = class_base(Q, seg, CLS);
     uint32_t n_shaded = 0, texel_fetches = 0;
     // shading cost is uniform per hit: waves walk the class queue in fixed 64-entry strides
@@ -393,114 +498,117 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, Queues Q, uint32_t 
         uint32_t src = hq[ii];
         PathState p = unpack_ray(rq[0][src], rq[1][src], rq[2][src]);
         float4 dcol = Q.hitd[src];
-        float t = dcol.x;
-        uint32_t prim = __float_as_uint(dcol.y);
-        // the material's parameters (metal, dielectric) or the record of its texture (the textured kinds)
-        const uint4 rec0 = S.prim_shade[2 * (size_t)prim], rec1 = S.prim_shade[2 * (size_t)prim + 1];
-        uint32_t key = segment_key(p.k0, p.k1, seg);
         if (valid) n_shaded++;
-
-        if (CLS == CLS_LIGHT) {  // material/diffuse_light.rs:19-22; scatter() is the default None
-            HitD h = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, false);
-            V3 e = texture_value<NOISE>(
-                S, rec0, rec1, h.p,
-                [&](float &u, float &v) {
-                    HitD hu = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, true);
-                    u = hu.u;
-                    v = hu.v;
-                },
-                texel_fetches);
-            if (!h.front) e = v3(0, 0, 0);
-            if (valid) Q.rad[p.slot] = make_float4(p.thr.x * e.x, p.thr.y * e.y, p.thr.z * e.z, 0.0f);
-            continue;
-        }
-
-        V3 coef, dir;
-        HitD h;
-        if (CLS == CLS_LAMBERT || CLS == CLS_LAMBERT_NOISE) {  // material/lambertian.rs:36-46
-            h = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, false);
-            V3 attenuation = texture_value<NOISE>(
-                S, rec0, rec1, h.p,
-                [&](float &u, float &v) {
-                    HitD hu = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, true);
-                    u = hu.u;
-                    v = hu.v;
-                },
-                texel_fetches);
-            V3 d_cos = cosine_generate(h.normal, draw(key, DIM_SCATTER + 4), draw(key, DIM_SCATTER + 5));
-            if (S.n_lights != 0) {  // renderer.rs:234-244, pdf/mixture.rs:22-32, hittables/group.rs:91-95
-                bool pick_light = draw(key, DIM_SCATTER + 0) < 0.5f;
-                uint32_t li = (uint32_t)(((unsigned long long)draw_u32(key, DIM_SCATTER + 1) * S.n_lights) >> 32);
-                V3 d_light = light_generate(S, S.lights[li], h.p, draw(key, DIM_SCATTER + 2), draw(key, DIM_SCATTER + 3));
-                dir = pick_light ? d_light : d_cos;
-                float pdf_v = cosine_value(h.normal, dir);
-                float mix_v = 0.5f * lights_value(S, h.p, dir) + 0.5f * pdf_v;
-                coef = attenuation * pdf_v / mix_v;
-            } else {  // renderer.rs:245-255
-                dir = d_cos;
-                coef = attenuation;
-            }
-        } else if (CLS == CLS_METAL) {  // material/metal.rs:31-46, random_in_unit_sphere random.rs:53-65
-            h = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, false);
-            V3 reflected = reflect(p.d, h.normal);
-            float fuzz = __uint_as_float(rec1.y);
-            V3 ball = v3(0, 0, 0);
-            if (fuzz != 0.0f) {
-                float theta = TWO_PI * draw(key, DIM_SCATTER + 0);
-                float cos_phi = -1.0f + 2.0f * draw(key, DIM_SCATTER + 1);
-                float r = powf(draw(key, DIM_SCATTER + 2), 1.0f / 3.0f);
-                float sin_phi = sqrtf(1.0f - cos_phi * cos_phi);
-                float sn, cs;
-                sincosf(theta, &sn, &cs);
-                ball = v3(r * sin_phi * cs, r * sin_phi * sn, r * cos_phi);
-            }
-            dir = normalize(reflected + ball * fuzz);
-            coef = v3(__uint_as_float(rec0.z), __uint_as_float(rec0.w), __uint_as_float(rec1.x));
-        } else if (CLS == CLS_DIELECTRIC) {  // material/dielectric.rs:33-60
-            h = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, false);
-            float ir = __uint_as_float(rec1.z);
-            float ratio = h.front ? 1.0f / ir : ir;
-            float cos_theta = -dot(p.d, h.normal);
-            float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
-            bool cannot_refract = ratio * sin_theta > 1.0f;
-            cannot_refract = cannot_refract || reflectance(cos_theta, ratio) > draw(key, DIM_SCATTER + 0);
-            dir = cannot_refract ? reflect(p.d, h.normal) : refract(p.d, h.normal, ratio);
-            coef = v3(1, 1, 1);
-        } else {  // CLS_ISOTROPIC: material/isotropic.rs:26-43, random_on_unit_sphere random.rs:41-51
-            h = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, false);
-            float z = -1.0f + 2.0f * draw(key, DIM_SCATTER + 0);
-            float theta = TWO_PI * draw(key, DIM_SCATTER + 1);
-            float xy = sqrtf(1.0f - z * z);
-            float sn, cs;
-            sincosf(theta, &sn, &cs);
-            dir = v3(cs * xy, sn * xy, z);
-            coef = texture_value<NOISE>(
-                S, rec0, rec1, h.p,
-                [&](float &u, float &v) {
-                    HitD hu = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, true);
-                    u = hu.u;
-                    v = hu.v;
-                },
-                texel_fetches);
-        }
         PathState q;
-        q.o = h.p;
-        q.d = dir;
-        q.thr = p.thr * coef;
-        q.slot = p.slot;
-        q.k0 = p.k0;
-        q.k1 = p.k1;
-        if (last) {  // renderer.rs:128-130: the depth budget is spent, the child returns `environment`
-            if (valid) Q.rad[p.slot] = make_float4(q.thr.x * S.env[0], q.thr.y * S.env[1], q.thr.z * S.env[2], 0.0f);
-        } else if (valid) {
-            store_ray(out, out_base + i, q);  // hit i of this class -> ray out_base + i of the next segment
-        }
+        float4 rad;
+        uint32_t fetched = 0;
+        bool goes_on = shade_hit<CLS, NOISE>(S, p, dcol, seg, fetched, q, rad);
+        if (!valid) continue;  // a lane past the end of the queue shaded a copy of the last hit
+        texel_fetches += fetched;
+        if (goes_on) store_ray(out, out_base + i, q);  // hit i of this class -> ray out_base + i of the next segment
+        else Q.rad[p.slot] = rad;
     }
     if (COUNT) {
         unsigned long long s = wave_sum(n_shaded), x = wave_sum(texel_fetches);
         if (lane_id() == 0) {
             atomicAdd(&Q.stats[4], s);
             atomicAdd(&Q.stats[5], x);
+        }
+    }
+}
+
+// The tail of a batch.  After a dozen segments a fraction of a percent of the paths is still alive, but the
+// depth budget (renderer.rs:128) may run to 50: launching the trace and shading kernels for each of those
+// segments costs more in launches than in work.  From segment `seg0` on, one launch finishes the paths: a lane takes
+// a ray of the queue and follows its path -- closest hit, shading, next ray -- to its end, then takes another.  The hit and the
+// shading are the functions the per-segment kernels call, with the same random streams, so the image does
+// not depend on where the tail starts.
+template <int CLS, bool NOISE>
+V4R_DEV void tail_shade(const SceneDev &S, const Queues &Q, uint32_t cls, float4 dcol, uint32_t seg, PathState &p, bool &alive, uint32_t &n_shaded,
+                        uint32_t &texel_fetches) {
+    if (__ballot(cls == (uint32_t)CLS) == 0ull) return;
+    if (cls == (uint32_t)CLS) {
+        PathState q;
+        float4 rad;
+        n_shaded++;
+        if (shade_hit<CLS, NOISE>(S, p, dcol, seg, texel_fetches, q, rad)) {
+            p = q;
+        } else {
+            Q.rad[p.slot] = rad;
+            alive = false;
+        }
+    }
+}
+template <bool COUNT, bool MEDIA, bool NOISE>
+__global__ __launch_bounds__(BLOCK) void k_tail(SceneDev S, Queues Q, uint32_t seg0) {
+    __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
+    Stack st;
+    st.lds = (lds_uint2 *)lds_stack + threadIdx.x;
+    st.stride = BLOCK;
+    st.spill = Q.spill + (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    st.spill_stride = Q.spill_stride;
+    st.sp = 0;
+    const uint32_t n_in = rays_in(Q, seg0);
+    float4 *const *rq = Q.ray[seg0 & 1u];
+    TraceCounters cnt;
+    uint32_t n_traced = 0, n_shaded = 0, texel_fetches = 0;
+    // A wave keeps its lanes busy: whenever paths have ended, the free lanes take the next rays of the queue
+    // (one atomic per wave and refill), so a wave is not held by its longest path while the queue has rays.
+    uint32_t *cursor = &Q.ctr[seg0].trace_cursor;  // no k_trace launch uses the cursor of this segment
+    bool alive = false, queue_empty = false;
+    PathState p;
+    p.o = p.d = p.thr = v3(0, 0, 0);
+    p.slot = p.k0 = p.k1 = 0u;
+    uint32_t seg = seg0;
+    while (true) {
+        const unsigned long long free_lanes = __ballot(!alive);
+        if (!queue_empty && free_lanes != 0ull) {
+            const uint32_t n_free = (uint32_t)__popcll(free_lanes);
+            uint32_t first = 0;
+            if (lane_id() == 0) first = atomicAdd(cursor, n_free);
+            first = __shfl(first, 0, 64);
+            const uint32_t i = first + (uint32_t)__popcll(free_lanes & ((1ull << lane_id()) - 1ull));
+            if (!alive && i < n_in) {
+                p = unpack_ray(rq[0][i], rq[1][i], rq[2][i]);
+                seg = seg0;
+                alive = true;
+            }
+            queue_empty = first + n_free >= n_in;
+        }
+        if (__ballot(alive) == 0ull) break;  // every path ends at the latest when shade_hit sees the last segment of the depth budget
+        Best best;
+        best.t = V4R_INF;
+        best.prim = NO_PRIM;
+        best.u = best.v = 0.0f;
+        auto key = [&]() { return segment_key(p.k0, p.k1, seg); };
+        traverse<COUNT, MEDIA>(S, p.o, p.d, alive, st, best, cnt, key, 0u);
+        if (alive) {
+            if (COUNT) n_traced++;
+            if (best.prim == NO_PRIM) {  // renderer.rs:184: a miss takes the background colour
+                Q.rad[p.slot] = make_float4(p.thr.x * S.bg[0], p.thr.y * S.bg[1], p.thr.z * S.bg[2], 0.0f);
+                alive = false;
+            }
+        }
+        const uint32_t cls = alive ? S.prim_info[best.prim] >> 24 : 0xFFu;
+        const float4 dcol = make_float4(best.t, __uint_as_float(best.prim), best.u, best.v);
+        tail_shade<CLS_LIGHT, NOISE>(S, Q, cls, dcol, seg, p, alive, n_shaded, texel_fetches);
+        tail_shade<CLS_LAMBERT, false>(S, Q, cls, dcol, seg, p, alive, n_shaded, texel_fetches);
+        tail_shade<CLS_LAMBERT_NOISE, NOISE>(S, Q, cls, dcol, seg, p, alive, n_shaded, texel_fetches);
+        tail_shade<CLS_METAL, false>(S, Q, cls, dcol, seg, p, alive, n_shaded, texel_fetches);
+        tail_shade<CLS_DIELECTRIC, false>(S, Q, cls, dcol, seg, p, alive, n_shaded, texel_fetches);
+        tail_shade<CLS_ISOTROPIC, NOISE>(S, Q, cls, dcol, seg, p, alive, n_shaded, texel_fetches);
+        ++seg;
+    }
+    if (COUNT) {
+        unsigned long long s = wave_sum(n_traced), n = wave_sum(cnt.nodes), q = wave_sum(cnt.prims), h = wave_sum(n_shaded), x = wave_sum(texel_fetches);
+        if (lane_id() == 0) {
+            atomicAdd(&Q.stats[0], s);
+            atomicAdd(&Q.stats[1], n);
+            atomicAdd(&Q.stats[2], q);
+            atomicAdd(&Q.stats[4], h);
+            atomicAdd(&Q.stats[5], x);
+            atomicAdd(&Q.stats[6], (unsigned long long)cnt.wave_steps);
+            atomicAdd(&Q.stats[7], (unsigned long long)cnt.wave_leaves);
         }
     }
 }
@@ -622,7 +730,9 @@ struct v4r_renderer {
     float *accum_own = nullptr, *accum = nullptr;
     uint8_t *tonemap_buf = nullptr;
     uint32_t npix = 0, n_passes = 0, batch_passes = 1;
-    uint32_t grid_trace = 0, grid_shade = 0, grid_stream = 0;
+    uint32_t grid_trace = 0, grid_shade = 0, grid_stream = 0, grid_tail = 0;
+    uint32_t tail_segment = 0;  // first segment that k_tail finishes in one launch; 0 = none
+    bool any_noise = false;
     bool counting = false;
     // HIP-event timing of the k_trace launches (v4r_profile_*)
     bool profiling = false;
@@ -1081,7 +1191,9 @@ int ensure_pipe(v4r_renderer *r, Pipe &pipe, size_t need) {
     if (int rc = alloc(&Q.given_up, need)) return rc;
     if (int rc = alloc(&Q.rad, need)) return rc;
     if (int rc = alloc(&Q.ctr, (size_t)r->max_depth + 1)) return rc;
-    HIP_TRY(hipMemset(Q.ctr, 0, r->ctr_bytes));
+    // in stream order: a null-stream hipMemset is not ordered against the non-blocking streams and could land
+    // in the middle of the pipeline's first batch
+    HIP_TRY(hipMemsetAsync(Q.ctr, 0, r->ctr_bytes, pipe.stream));
     Q.stats = r->stats;
     Q.spill_stride = (size_t)r->grid_trace * BLOCK;
     if (int rc = alloc(&Q.spill, Q.spill_stride * std::max(r->spill_depth, 1u))) return rc;
@@ -1194,6 +1306,14 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
                                  : std::max(std::max(grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, false, false, false>, n_cu), grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, false, true, false>, n_cu)), grid_for(k_trace_rays<false>, n_cu));
     r->grid_shade = (uint32_t)n_cu * 8u;
     r->grid_stream = (uint32_t)n_cu * 8u;
+    for (bool noise : r->class_noise) r->any_noise = r->any_noise || noise;
+    {
+        uint32_t g = r->has_media ? (r->any_noise ? grid_for(k_tail<false, true, true>, n_cu) : grid_for(k_tail<false, true, false>, n_cu))
+                                  : (r->any_noise ? grid_for(k_tail<false, false, true>, n_cu) : grid_for(k_tail<false, false, false>, n_cu));
+        r->grid_tail = std::min(g, r->grid_trace);  // the stack spill slab has one column per thread of a trace launch
+    }
+    r->tail_segment = 12;
+    if (const char *env = std::getenv("V4R_TAIL_SEGMENT")) r->tail_segment = (uint32_t)std::max(0, std::atoi(env));
     // a ray's stack holds at most three entries per level of the wide tree above its current node
     uint32_t stack_max = 3u * wide_depth + 1u;
     uint32_t spill_depth = stack_max > (uint32_t)LDS_DEPTH ? stack_max - LDS_DEPTH : 0;
@@ -1268,6 +1388,21 @@ void launch_shade(v4r_renderer *r, Pipe &pipe, uint32_t seg) {
     }
 }
 
+void launch_tail(v4r_renderer *r, Pipe &pipe, uint32_t seg) {
+    dim3 grid(r->grid_tail), block(BLOCK);
+    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, block, 0, pipe.stream, r->S, pipe.Q, seg); };
+    switch ((r->counting ? 4 : 0) | (r->has_media ? 2 : 0) | (r->any_noise ? 1 : 0)) {
+        case 0: launch(k_tail<false, false, false>); break;
+        case 1: launch(k_tail<false, false, true>); break;
+        case 2: launch(k_tail<false, true, false>); break;
+        case 3: launch(k_tail<false, true, true>); break;
+        case 4: launch(k_tail<true, false, false>); break;
+        case 5: launch(k_tail<true, false, true>); break;
+        case 6: launch(k_tail<true, true, false>); break;
+        default: launch(k_tail<true, true, true>); break;
+    }
+}
+
 int run_batch(v4r_renderer *r, Pipe &pipe, uint64_t seed, uint32_t first_pass, uint32_t pass_stride, uint32_t n_batch_passes, uint32_t row0,
               uint32_t n_rows) {
     const uint32_t band_pix = n_rows * r->S.width, band_offset = row0 * r->S.width;
@@ -1288,7 +1423,10 @@ int run_batch(v4r_renderer *r, Pipe &pipe, uint64_t seed, uint32_t first_pass, u
         order.full_groups = n_batch_passes >> lp;
     }
     PrimaryArgs primary{(uint32_t)seed, (uint32_t)(seed >> 32), first_pass, pass_stride, n_paths, band_pix, band_offset, order};
-    for (uint32_t seg = 0; seg < r->S.max_depth; ++seg) {
+    // segments 0 .. n_wavefront-1 run as one trace launch (or two) and one shading launch per class; one k_tail finishes the rest
+    const uint32_t n_wavefront = r->tail_segment >= 1u && r->tail_segment < r->S.max_depth ? r->tail_segment : r->S.max_depth;
+    for (uint32_t seg = 0; seg <= n_wavefront && seg < r->S.max_depth; ++seg) {
+        const bool tail = seg == n_wavefront;
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         if (r->profiling) {
             if (r->ev_used + 2 > r->ev_pool.size()) {
@@ -1302,8 +1440,10 @@ int run_batch(v4r_renderer *r, Pipe &pipe, uint64_t seed, uint32_t first_pass, u
             ev1 = r->ev_pool[r->ev_used++];
             HIP_TRY(hipEventRecord(ev0, pipe.stream));
         }
-        launch_trace(r, pipe, seg, primary);
+        if (tail) launch_tail(r, pipe, seg);  // timed with the trace launches: nearly all of it is traversal
+        else launch_trace(r, pipe, seg, primary);
         if (r->profiling) HIP_TRY(hipEventRecord(ev1, pipe.stream));
+        if (tail) break;
         launch_shade<CLS_LIGHT>(r, pipe, seg);
         launch_shade<CLS_LAMBERT>(r, pipe, seg);
         launch_shade<CLS_LAMBERT_NOISE>(r, pipe, seg);
@@ -1471,7 +1611,8 @@ int v4r_accum_write(v4r_renderer *r, const float *host_hwc, uint32_t n_passes) {
     if (!r || !host_hwc) return set_error(V4R_E_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(hipStreamSynchronize(r->stream));
-    HIP_TRY(hipMemcpy(r->accum, host_hwc, (size_t)r->npix * 3 * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(r->accum, host_hwc, (size_t)r->npix * 3 * sizeof(float), hipMemcpyHostToDevice, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));  // the caller may reuse host_hwc; later passes are ordered after the copy
     r->n_passes = n_passes;
     return V4R_OK;
 }
@@ -1511,8 +1652,8 @@ static int trace_common(v4r_renderer *r, uint32_t n, const float *host_origin, c
     if (host_origin) {
         e = hipMalloc((void **)&d_o, (size_t)n * 3 * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void **)&d_d, (size_t)n * 3 * sizeof(float));
-        if (e == hipSuccess) e = hipMemcpy(d_o, host_origin, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(d_d, host_dir, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_o, host_origin, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, r->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_d, host_dir, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, r->stream);
     }
     if (e == hipSuccess) e = hipMalloc((void **)&d_t, (size_t)n * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&d_p, (size_t)n * sizeof(uint32_t));
@@ -1565,7 +1706,10 @@ int v4r_stats_read(v4r_renderer *r, v4r_stats *out, int reset) {
     out->texel_fetches = h[5];
     out->wave_node_steps = h[6];
     out->wave_leaf_steps = h[7];
-    if (reset) HIP_TRY(hipMemset(r->stats, 0, 64));
+    if (reset) {
+        HIP_TRY(hipMemsetAsync(r->stats, 0, 64, r->stream));  // ordered before whatever is rendered next
+        HIP_TRY(hipStreamSynchronize(r->stream));
+    }
     return V4R_OK;
 }
 

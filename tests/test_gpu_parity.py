@@ -314,6 +314,55 @@ def test_second_trace_launch_changes_nothing(name, monkeypatch):
         r2.close()
 
 
+@pytest.mark.parametrize("name", ["c1", "c2", "c5"])
+def test_tail_kernel_changes_nothing(name, monkeypatch):
+    """From some segment on, one launch follows each remaining path to its end instead of one trace launch and
+    one shading launch per class and segment: the image is bit-identical wherever that tail starts (1 = right
+    after the camera rays, 0 = never), and so are the work counters."""
+    scene, r = make(name)
+    r.enable_stats(True)
+    r.render_passes(3)
+    ref, _ = r.read_accumulator()
+    ref_stats = r.read_stats()
+    r.close()
+    monkeypatch.setenv("V4R_GIVE_UP_LANES", "0")   # a second trace launch re-enters the tree: node counts would differ
+    full = None
+    for start in ("0", "1", "2", "7", "49", "50", "1000"):
+        monkeypatch.setenv("V4R_TAIL_SEGMENT", start)
+        r2 = Renderer(scene.renderer_param, scene.camera_param, scene)
+        r2.enable_stats(True)
+        r2.render_passes(3)
+        img, _ = r2.read_accumulator()
+        stats = r2.read_stats()
+        r2.close()
+        assert np.array_equal(img, ref), start
+        for field in ("segments", "paths", "shaded"):
+            assert stats[field] == ref_stats[field], (start, field)
+        full = full or stats
+        for field in ("nodes", "prims", "texel_fetches"):
+            assert stats[field] == full[field], (start, field)
+
+
+def test_first_batches_of_fresh_pipelines_are_complete(monkeypatch):
+    """The pipelines of a renderer get their queues at first use, while other pipelines are already running:
+    nothing of that set-up may land in the middle of a batch.  (A null-stream memset of a new pipeline's
+    counters once did; many launches per batch made it likely.)"""
+    monkeypatch.setenv("V4R_GIVE_UP_LANES", "0")
+    monkeypatch.setenv("V4R_TAIL_SEGMENT", "0")
+    ref = ref_stats = None
+    for _ in range(8):
+        scene, r = make("c2")
+        r.enable_stats(True)
+        r.render_passes(3)
+        img, _ = r.read_accumulator()
+        stats = r.read_stats()
+        r.close()
+        if ref is None:
+            ref, ref_stats = img, stats
+        assert np.array_equal(img, ref)
+        assert {k: stats[k] for k in ("segments", "nodes", "prims", "shaded")} == {k: ref_stats[k] for k in ("segments", "nodes", "prims", "shaded")}
+
+
 def test_row_bands_add_up_to_the_full_image():
     """Tile split: bands of rows rendered separately (any heights, any order) are exactly the rows of the
     full-image render, because a pixel's random streams are keyed by its position in the whole image."""
