@@ -539,8 +539,11 @@ V4R_DEV void tail_shade(const SceneDev &S, const Queues &Q, uint32_t cls, float4
         }
     }
 }
+#ifndef V4R_TAIL_MIN_WAVES_NOISE
+#define V4R_TAIL_MIN_WAVES_NOISE 3  // the Perlin code alone needs ~150 VGPRs; unforced the kernel has 172-196 (2 waves/SIMD)
+#endif
 template <bool COUNT, bool MEDIA, bool NOISE>
-__global__ __launch_bounds__(BLOCK) void k_tail(SceneDev S, Queues Q, uint32_t seg0) {
+__global__ __launch_bounds__(BLOCK, NOISE ? V4R_TAIL_MIN_WAVES_NOISE : 1) void k_tail(SceneDev S, Queues Q, uint32_t seg0) {
     __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
     Stack st;
     st.lds = (lds_uint2 *)lds_stack + threadIdx.x;
@@ -1312,7 +1315,9 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
                                   : (r->any_noise ? grid_for(k_tail<false, false, true>, n_cu) : grid_for(k_tail<false, false, false>, n_cu));
         r->grid_tail = std::min(g, r->grid_trace);  // the stack spill slab has one column per thread of a trace launch
     }
-    r->tail_segment = 12;
+    // measured: +2 % (spheres) to +5 % (bunny) with the tail from segment 12; the variants that carry the medium or the
+    // Perlin code (3 waves/SIMD) only pay off later (C1 +1.5 % from 24, -3 % from 12)
+    r->tail_segment = r->has_media || r->any_noise ? 24 : 12;
     if (const char *env = std::getenv("V4R_TAIL_SEGMENT")) r->tail_segment = (uint32_t)std::max(0, std::atoi(env));
     // a ray's stack holds at most three entries per level of the wide tree above its current node
     uint32_t stack_max = 3u * wide_depth + 1u;
