@@ -363,6 +363,28 @@ def test_first_batches_of_fresh_pipelines_are_complete(monkeypatch):
         assert {k: stats[k] for k in ("segments", "nodes", "prims", "shaded")} == {k: ref_stats[k] for k in ("segments", "nodes", "prims", "shaded")}
 
 
+def test_batching_knobs_change_nothing(monkeypatch):
+    """Batch size, number of pipelines and the tiling of the camera-ray order decide where and when a path is
+    computed, never what it computes: 37 passes of an odd-sized image are bit-identical under all of them."""
+    scene = scenes.load("c2", 253, 141)
+    def render():
+        r = Renderer(scene.renderer_param, scene.camera_param, scene)
+        r.render_passes(37)
+        img, n = r.read_accumulator()
+        r.close()
+        assert n == 37
+        return img
+    ref = render()
+    for knobs in ({"V4R_PIPES": "1"}, {"V4R_PIPES": "4", "V4R_BATCH_PATHS": str(253 * 141 * 5)}, {"V4R_BATCH_PATHS": "1"},
+                  {"V4R_TILE_PASSES_LOG2": "0"}, {"V4R_TILE_PASSES_LOG2": "6", "V4R_BATCH_PATHS": str(253 * 141 * 64)},
+                  {"V4R_PIPES": "2", "V4R_TILE_PASSES_LOG2": "2", "V4R_TAIL_SEGMENT": "3", "V4R_GIVE_UP_LANES": "30"}):
+        for k, v in knobs.items():
+            monkeypatch.setenv(k, v)
+        assert np.array_equal(render(), ref), knobs
+        for k in knobs:
+            monkeypatch.delenv(k)
+
+
 def test_row_bands_add_up_to_the_full_image():
     """Tile split: bands of rows rendered separately (any heights, any order) are exactly the rows of the
     full-image render, because a pixel's random streams are keyed by its position in the whole image."""
