@@ -236,7 +236,14 @@ __global__ __launch_bounds__(BLOCK, MEDIA ? V4R_TRACE_MIN_WAVES_MEDIA : V4R_TRAC
     __shared__ uint32_t s_base;
     __shared__ uint32_t s_cnt[CLS_COUNT + 1];  // [CLS_COUNT]: rays given up
     __shared__ uint32_t s_where[RAYS_PER_THREAD * BLOCK];  // per ray of the chunk: class << 16 | rank among the chunk's hits of that class
+    __shared__ v4f s_top[8 * TOP_NODES];
+    if (threadIdx.x < 8u * S.n_top_nodes) {
+        float4 v = S.nodes4[threadIdx.x];
+        s_top[threadIdx.x] = v4f{v.x, v.y, v.z, v.w};
+    }
     Stack st;
+    st.top = (const lds_v4f *)s_top;
+    st.n_top = S.n_top_nodes;
     st.lds = (lds_uint2 *)lds_stack + threadIdx.x;
     st.stride = BLOCK;
     st.spill = Q.spill + (size_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -1054,8 +1061,9 @@ void rebuild_binary(const v4r_scene_desc *d, std::vector<v4r_bvh_node> &out) {
 // by that child's two children.  Leaves stay single primitives, so the set of (ray, primitive) tests
 // that can happen is the one of the binary tree.  Nodes are emitted parent before children, siblings
 // next to each other.
-uint32_t collapse_to_wide(const v4r_scene_desc *d, const v4r_bvh_node *nodes, uint32_t n_nodes, std::vector<float4> &out) {
+uint32_t collapse_to_wide(const v4r_scene_desc *d, const v4r_bvh_node *nodes, uint32_t n_nodes, std::vector<float4> &out, uint32_t &n_top) {
     out.clear();
+    n_top = 0;
     if (n_nodes == 0) return 0;
     // which subtrees of the binary tree hold a constant medium (wide_step must not cull those by distance)
     std::vector<uint8_t> holds_medium(n_nodes, 0);
@@ -1102,13 +1110,25 @@ uint32_t collapse_to_wide(const v4r_scene_desc *d, const v4r_bvh_node *nodes, ui
     struct Task {
         uint32_t binary, wide, depth;
     };
-    std::vector<Task> todo{{0u, 0u, 1u}};
+    // Node order: the top TOP_LEVELS levels breadth first (they are the prefix that k_trace copies into LDS), the
+    // rest depth first (a subtree stays together in memory).
+    std::vector<Task> todo;          // depth first: taken from the back
+    std::vector<Task> top{{0u, 0u, 1u}};  // breadth first: taken from the front, all before `todo`
+    size_t top_next = 0;
     uint32_t depth = 0;
     out.resize(8);
     const float inf = std::numeric_limits<float>::infinity();
-    while (!todo.empty()) {
-        Task t = todo.back();
-        todo.pop_back();
+    while (top_next < top.size() || !todo.empty()) {
+        Task t;
+        const bool from_top = top_next < top.size();
+        if (from_top) {
+            t = top[top_next++];
+        } else {
+            t = todo.back();
+            todo.pop_back();
+        }
+        // the children of levels < TOP_LEVELS are numbered (and expanded) breadth first, before anything deeper
+        std::vector<Task> &next = from_top && t.depth < (uint32_t)TOP_LEVELS ? top : todo;
         depth = std::max(depth, t.depth);
         Item items[4];
         int n = 2;
@@ -1146,7 +1166,7 @@ uint32_t collapse_to_wide(const v4r_scene_desc *d, const v4r_bvh_node *nodes, ui
             else {
                 child[k] = (uint32_t)(out.size() / 8);
                 out.resize(out.size() + 8);
-                todo.push_back({items[k].child, child[k], t.depth + 1u});
+                next.push_back({items[k].child, child[k], t.depth + 1u});
             }
         }
         float4 *w = out.data() + 8 * (size_t)t.wide;
@@ -1161,6 +1181,7 @@ uint32_t collapse_to_wide(const v4r_scene_desc *d, const v4r_bvh_node *nodes, ui
         std::memcpy(&mask_bits, &mask, 4);
         w[7] = make_float4(mask_bits, 0.0f, 0.0f, 0.0f);
     }
+    n_top = (uint32_t)top.size();  // one task per node of the top levels; they were numbered first
     return depth;  // in wide nodes, root = 1
 }
 
@@ -1219,9 +1240,9 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
         if (!(d->flags & V4R_FLAG_KEEP_HOST_BVH) && d->n_nodes > 0) {
             std::vector<v4r_bvh_node> better;
             rebuild_binary(d, better);
-            wide_depth = collapse_to_wide(d, better.data(), (uint32_t)better.size(), wide);
+            wide_depth = collapse_to_wide(d, better.data(), (uint32_t)better.size(), wide, S.n_top_nodes);
         } else {
-            wide_depth = collapse_to_wide(d, d->nodes, d->n_nodes, wide);
+            wide_depth = collapse_to_wide(d, d->nodes, d->n_nodes, wide, S.n_top_nodes);
         }
         if (int rc = r->upload(&S.nodes4, wide.data(), wide.size())) return rc;
     }

@@ -38,6 +38,7 @@ struct SceneDev {
     const uint8_t *perlin_perm;  // 768 bytes per table: perm_x, perm_y, perm_z
     const uint32_t *lights;      // primitive indices
     uint32_t n_nodes, n_prims, n_lights, flags;
+    uint32_t n_top_nodes;        // the first n_top_nodes wide nodes are the top levels of the tree (breadth first): k_trace keeps them in LDS
     float bg[3], env[3];
     v4r_camera cam;
     uint32_t width, height, max_depth, antialias;
@@ -227,7 +228,15 @@ constexpr int LDS_DEPTH = V4R_LDS_DEPTH;
 // The LDS part is addressed through an LDS-typed pointer: through a generic one the compiler merges
 // the two halves of push/pop into flat loads and stores, which are slower and wait on both counters.
 typedef __attribute__((address_space(3))) uint2 lds_uint2;
+// Top of the tree in LDS (TOP_LEVELS levels, at most TOP_NODES nodes): every ray starts there, and an LDS read has
+// a fraction of the latency of a vector-memory read that hits in L1 and does not occupy the texture addresser.
+constexpr int TOP_LEVELS = 3;
+constexpr int TOP_NODES = 1 + 4 + 16;
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4f lds_v4f;
 struct Stack {
+    const lds_v4f *top = nullptr;  // 8 vectors per node, nodes 0 .. n_top-1; n_top = 0: no copy in LDS
+    uint32_t n_top = 0;
     lds_uint2 *lds;    // this thread's column: lds[e * block_dim]
     uint32_t stride;   // block_dim
     uint2 *spill;      // this thread's column in the global slab: spill[e * spill_stride]
@@ -319,10 +328,21 @@ V4R_DEV void wide_pop(Stack &st, float best_t, Wide &W) {
 // culled by distance: they are entered whenever the ray meets their box and carry entry distance -inf.
 template <bool COUNT, bool MEDIA>
 V4R_DEV void wide_step(const SceneDev &S, V3 o, V3 inv, Stack &st, const Best &best, Wide &W, TraceCounters &cnt) {
-    const float4 *np = S.nodes4 + 8 * (size_t)W.cur;
-    float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5];
-    float4 kids = np[6];
-    const uint32_t never_cull = MEDIA ? __float_as_uint(np[7].x) : 0u;
+    float4 lx, ly, lz, hx, hy, hz, kids;
+    uint32_t never_cull = 0u;
+    if (W.cur < st.n_top) {
+        const lds_v4f *tp = st.top + 8u * W.cur;
+        auto ld = [&](int k) {
+            v4f v = tp[k];
+            return make_float4(v.x, v.y, v.z, v.w);
+        };
+        lx = ld(0), ly = ld(1), lz = ld(2), hx = ld(3), hy = ld(4), hz = ld(5), kids = ld(6);
+        if (MEDIA) never_cull = __float_as_uint(tp[7].x);
+    } else {
+        const float4 *np = S.nodes4 + 8 * (size_t)W.cur;
+        lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5], kids = np[6];
+        if (MEDIA) never_cull = __float_as_uint(np[7].x);
+    }
     if (COUNT) cnt.nodes++;
     // Ray::intersects_aabb (ray.rs:167-189): the same running-interval test with strict tmin < tmax, the
     // per-axis divisions replaced by multiplications with a reciprocal computed once per ray; the interval
