@@ -237,9 +237,9 @@ __global__ __launch_bounds__(BLOCK, MEDIA ? V4R_TRACE_MIN_WAVES_MEDIA : V4R_TRAC
     __shared__ uint32_t s_cnt[CLS_COUNT + 1];  // [CLS_COUNT]: rays given up
     __shared__ uint32_t s_where[RAYS_PER_THREAD * BLOCK];  // per ray of the chunk: class << 16 | rank among the chunk's hits of that class
     __shared__ v4f s_top[8 * TOP_NODES];
-    if (threadIdx.x < 8u * S.n_top_nodes) {
-        float4 v = S.nodes4[threadIdx.x];
-        s_top[threadIdx.x] = v4f{v.x, v.y, v.z, v.w};
+    for (uint32_t k = threadIdx.x; k < 8u * S.n_top_nodes; k += BLOCK) {
+        float4 v = S.nodes4[k];
+        s_top[k] = v4f{v.x, v.y, v.z, v.w};
     }
     Stack st;
     st.top = (const lds_v4f *)s_top;

@@ -230,8 +230,11 @@ constexpr int LDS_DEPTH = V4R_LDS_DEPTH;
 typedef __attribute__((address_space(3))) uint2 lds_uint2;
 // Top of the tree in LDS (TOP_LEVELS levels, at most TOP_NODES nodes): every ray starts there, and an LDS read has
 // a fraction of the latency of a vector-memory read that hits in L1 and does not occupy the texture addresser.
-constexpr int TOP_LEVELS = 3;
-constexpr int TOP_NODES = 1 + 4 + 16;
+#ifndef V4R_TOP_LEVELS
+#define V4R_TOP_LEVELS 3
+#endif
+constexpr int TOP_LEVELS = V4R_TOP_LEVELS;
+constexpr int TOP_NODES = TOP_LEVELS == 4 ? 85 : (TOP_LEVELS == 3 ? 21 : (TOP_LEVELS == 2 ? 5 : 1));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4f lds_v4f;
 struct Stack {
