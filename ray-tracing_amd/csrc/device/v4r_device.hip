@@ -200,6 +200,17 @@ V4R_DEV uint32_t class_base(const Queues &Q, uint32_t seg, int cls) {
     return n;
 }
 
+// Copies the top of the wide tree into the workgroup's LDS array and points the stack at it; the caller
+// synchronises the workgroup before the first traversal.
+V4R_DEV void stage_tree_top(const SceneDev &S, v4f *s_top, Stack &st) {
+    for (uint32_t k = threadIdx.x; k < 8u * S.n_top_nodes; k += BLOCK) {
+        float4 v = S.nodes4[k];
+        s_top[k] = v4f{v.x, v.y, v.z, v.w};
+    }
+    st.top = (const lds_v4f *)s_top;
+    st.n_top = S.n_top_nodes;
+}
+
 // BVH traversal + closest hit for the rays of one segment.  A workgroup takes RAYS_PER_THREAD*256 rays
 // at a time (the chunk at its own grid position first, then chunks from a shared cursor: one global
 // atomic per chunk); each lane traces RAYS_PER_THREAD rays of the chunk one after the other.  Within a
@@ -237,13 +248,8 @@ __global__ __launch_bounds__(BLOCK, MEDIA ? V4R_TRACE_MIN_WAVES_MEDIA : V4R_TRAC
     __shared__ uint32_t s_cnt[CLS_COUNT + 1];  // [CLS_COUNT]: rays given up
     __shared__ uint32_t s_where[RAYS_PER_THREAD * BLOCK];  // per ray of the chunk: class << 16 | rank among the chunk's hits of that class
     __shared__ v4f s_top[8 * TOP_NODES];
-    for (uint32_t k = threadIdx.x; k < 8u * S.n_top_nodes; k += BLOCK) {
-        float4 v = S.nodes4[k];
-        s_top[k] = v4f{v.x, v.y, v.z, v.w};
-    }
     Stack st;
-    st.top = (const lds_v4f *)s_top;
-    st.n_top = S.n_top_nodes;
+    stage_tree_top(S, s_top, st);  // the chunk loop below synchronises before the first traversal
     st.lds = (lds_uint2 *)lds_stack + threadIdx.x;
     st.stride = BLOCK;
     st.spill = Q.spill + (size_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -552,7 +558,10 @@ V4R_DEV void tail_shade(const SceneDev &S, const Queues &Q, uint32_t cls, float4
 template <bool COUNT, bool MEDIA, bool NOISE>
 __global__ __launch_bounds__(BLOCK, NOISE ? V4R_TAIL_MIN_WAVES_NOISE : 1) void k_tail(SceneDev S, Queues Q, uint32_t seg0) {
     __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
+    __shared__ v4f s_top[8 * TOP_NODES];
     Stack st;
+    stage_tree_top(S, s_top, st);
+    __syncthreads();
     st.lds = (lds_uint2 *)lds_stack + threadIdx.x;
     st.stride = BLOCK;
     st.spill = Q.spill + (size_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -660,7 +669,10 @@ template <bool MEDIA>
 __global__ __launch_bounds__(BLOCK) void k_trace_rays(SceneDev S, Queues Q, uint32_t n, const float *origin, const float *dir,
                                                       uint32_t seed_lo, uint32_t seed_hi, uint32_t *prim_out, float *t_out) {
     __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
+    __shared__ v4f s_top[8 * TOP_NODES];
     Stack st;
+    stage_tree_top(S, s_top, st);
+    __syncthreads();
     st.lds = (lds_uint2 *)lds_stack + threadIdx.x;
     st.stride = BLOCK;
     st.spill = Q.spill + (size_t)blockIdx.x * BLOCK + threadIdx.x;
