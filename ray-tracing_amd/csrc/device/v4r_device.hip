@@ -225,6 +225,9 @@ V4R_DEV void stage_tree_top(const SceneDev &S, v4f *s_top, Stack &st) {
 #ifndef V4R_TRACE_MIN_WAVES
 #define V4R_TRACE_MIN_WAVES 1  // tuning hook: forcing 6 waves/SIMD (80 VGPRs) spills and is not faster
 #endif
+#ifndef V4R_TRACE_MIN_WAVES_PRIMARY
+#define V4R_TRACE_MIN_WAVES_PRIMARY 5  // 109-113 VGPRs unforced (4 waves/SIMD); at 96 with 32-40 B of scratch: C4 +1-2 %, others flat
+#endif
 #ifndef V4R_TRACE_MIN_WAVES_MEDIA
 #define V4R_TRACE_MIN_WAVES_MEDIA 4  // the kernels with the constant-medium code need 133-143 VGPRs unforced (3 waves/SIMD)
 #endif
@@ -241,7 +244,7 @@ struct PrimaryArgs {
 // segment packed next to each other, starting from the closest hit they had found, and never gives up.
 // (SECOND is a template parameter because the extra index it carries costs the first launch an occupancy step.)
 template <bool COUNT, int RAYS_PER_THREAD, bool MEDIA, bool PRIMARY, bool SECOND>
-__global__ __launch_bounds__(BLOCK, MEDIA ? V4R_TRACE_MIN_WAVES_MEDIA : V4R_TRACE_MIN_WAVES) void k_trace(SceneDev S, Queues Q, uint32_t seg, PrimaryArgs A, uint32_t give_up_lanes) {
+__global__ __launch_bounds__(BLOCK, MEDIA ? V4R_TRACE_MIN_WAVES_MEDIA : (PRIMARY ? V4R_TRACE_MIN_WAVES_PRIMARY : V4R_TRACE_MIN_WAVES)) void k_trace(SceneDev S, Queues Q, uint32_t seg, PrimaryArgs A, uint32_t give_up_lanes) {
     constexpr bool second = SECOND;
     __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
     __shared__ uint32_t s_base;
