@@ -243,8 +243,8 @@ struct PrimaryArgs {
 // ranking as the hits); the second launch (SECOND) traces the given-up rays of the whole
 // segment packed next to each other, starting from the closest hit they had found, and never gives up.
 // (SECOND is a template parameter because the extra index it carries costs the first launch an occupancy step.)
-template <bool COUNT, int RAYS_PER_THREAD, bool MEDIA, bool PRIMARY, bool SECOND>
-__global__ __launch_bounds__(BLOCK, MEDIA ? V4R_TRACE_MIN_WAVES_MEDIA : (PRIMARY ? V4R_TRACE_MIN_WAVES_PRIMARY : V4R_TRACE_MIN_WAVES)) void k_trace(SceneDev S, Queues Q, uint32_t seg, PrimaryArgs A, uint32_t give_up_lanes) {
+template <bool COUNT, int RAYS_PER_THREAD, int MEDIA, bool PRIMARY, bool SECOND>
+__global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES_MEDIA : (PRIMARY || MEDIA == MEDIA_DIRECT ? V4R_TRACE_MIN_WAVES_PRIMARY : V4R_TRACE_MIN_WAVES)) void k_trace(SceneDev S, Queues Q, uint32_t seg, PrimaryArgs A, uint32_t give_up_lanes) {
     constexpr bool second = SECOND;
     __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
     __shared__ uint32_t s_base;
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(BLOCK, MEDIA ? V4R_TRACE_MIN_WAVES_MEDIA : (PRIMARY
                     }
                     return segment_key(k0, k1, seg);
                 };
-                bool gave_up = traverse<COUNT, MEDIA>(S, o, d, active, st, best, cnt, key, second ? 0u : give_up_lanes);
+                bool gave_up = traverse<COUNT, MEDIA>(S, o, d, active, st, best, cnt, key, second ? 0u : give_up_lanes, second);
                 uint32_t w = 0xFFFFFFFFu;
                 if (active && gave_up) {
                     Q.hitd[i] = make_float4(best.t, __uint_as_float(best.prim), best.u, best.v);
@@ -558,7 +558,7 @@ V4R_DEV void tail_shade(const SceneDev &S, const Queues &Q, uint32_t cls, float4
 #ifndef V4R_TAIL_MIN_WAVES_NOISE
 #define V4R_TAIL_MIN_WAVES_NOISE 3  // the Perlin code alone needs ~150 VGPRs; unforced the kernel has 172-196 (2 waves/SIMD)
 #endif
-template <bool COUNT, bool MEDIA, bool NOISE>
+template <bool COUNT, int MEDIA, bool NOISE>
 __global__ __launch_bounds__(BLOCK, NOISE ? V4R_TAIL_MIN_WAVES_NOISE : 1) void k_tail(SceneDev S, Queues Q, uint32_t seg0) {
     __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
     __shared__ v4f s_top[8 * TOP_NODES];
@@ -668,7 +668,7 @@ __global__ __launch_bounds__(BLOCK) void k_tonemap(const float *accum, size_t n,
 // Closest hit of explicit rays (or of the deterministic primary rays when origin == nullptr).
 // Ray i draws the free path of a constant medium from the stream of path (seed, pass 0, pixel i);
 // the deterministic primary rays use key 0.
-template <bool MEDIA>
+template <int MEDIA>
 __global__ __launch_bounds__(BLOCK) void k_trace_rays(SceneDev S, Queues Q, uint32_t n, const float *origin, const float *dir,
                                                       uint32_t seed_lo, uint32_t seed_hi, uint32_t *prim_out, float *t_out) {
     __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
@@ -766,7 +766,7 @@ struct v4r_renderer {
     double trace_ms = 0.0;
     uint64_t trace_launches = 0;
     bool has_class[CLS_COUNT] = {false, false, false, false, false, false};
-    bool has_media = false;  // selects the kernels that carry the constant-medium test
+    int media_mode = MEDIA_NONE;  // selects the kernel instantiations (see traverse)
     bool class_noise[CLS_COUNT] = {false, false, false, false, false, false};  // a material of the class uses a noise texture
     uint32_t give_up_lanes = 0, give_up_segments = 0;  // see k_trace
     size_t ctr_bytes = 0;
@@ -940,7 +940,7 @@ uint32_t grid_for(K kernel, int n_cu) {
 // node format of the ABI.  The reference's builder (bvh.rs:84-141: 6 buckets, widest centroid axis
 // only, squared-extent "area") stays the host's; the closest hit does not depend on the tree, and
 // rays visit 5-15 % fewer nodes in this one.  V4R_FLAG_KEEP_HOST_BVH skips it.
-void rebuild_binary(const v4r_scene_desc *d, std::vector<v4r_bvh_node> &out) {
+void rebuild_binary(const v4r_scene_desc *d, bool without_media, std::vector<v4r_bvh_node> &out) {
     struct Box {
         float lo[3], hi[3];
     };
@@ -977,15 +977,17 @@ void rebuild_binary(const v4r_scene_desc *d, std::vector<v4r_bvh_node> &out) {
         float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
         return dx * dy + dy * dz + dz * dx;
     };
-    std::vector<uint32_t> order(d->n_prims);
-    for (uint32_t i = 0; i < d->n_prims; ++i) order[i] = i;
+    std::vector<uint32_t> order;
+    order.reserve(d->n_prims);
+    for (uint32_t i = 0; i < d->n_prims; ++i)
+        if (!without_media || (d->prims[i].type & V4R_PRIM_TYPE_MASK) != V4R_PRIM_MEDIUM) order.push_back(i);
     out.clear();
     out.reserve(d->n_nodes);
     struct Task {
         uint32_t begin, end, node;
         int slot;  // which child word of `node` receives this range (-1: the root)
     };
-    std::vector<Task> todo{{0u, d->n_prims, 0u, -1}};
+    std::vector<Task> todo{{0u, (uint32_t)order.size(), 0u, -1}};
     constexpr int BINS = 16;
     while (!todo.empty()) {
         Task t = todo.back();
@@ -1252,9 +1254,21 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     SceneDev &S = r->S;
     {
         std::vector<float4> wide;
+        // A few constant media are tested directly, before the tree, by the kernels without the medium code in their
+        // traversal (see traverse): the tree is then built over the other primitives.
+        std::vector<uint32_t> media_list;
+        for (uint32_t i = 0; i < d->n_prims; ++i)
+            if ((d->prims[i].type & V4R_PRIM_TYPE_MASK) == V4R_PRIM_MEDIUM) media_list.push_back(i);
+        const bool direct = !(d->flags & V4R_FLAG_KEEP_HOST_BVH) && !media_list.empty() && media_list.size() <= MAX_DIRECT_MEDIA &&
+                            d->n_prims - media_list.size() >= 2;
+        if (direct) {
+            if (int rc = r->upload(&S.media_direct, media_list.data(), media_list.size())) return rc;
+            S.n_media_direct = (uint32_t)media_list.size();
+        }
+        r->media_mode = direct ? MEDIA_DIRECT : (d->n_media != 0 ? MEDIA_IN_TREE : MEDIA_NONE);
         if (!(d->flags & V4R_FLAG_KEEP_HOST_BVH) && d->n_nodes > 0) {
             std::vector<v4r_bvh_node> better;
-            rebuild_binary(d, better);
+            rebuild_binary(d, direct, better);
             wide_depth = collapse_to_wide(d, better.data(), (uint32_t)better.size(), wide, S.n_top_nodes);
         } else {
             wide_depth = collapse_to_wide(d, d->nodes, d->n_nodes, wide, S.n_top_nodes);
@@ -1313,7 +1327,6 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     if (int rc = r->upload(&S.perlin_perm, pperm.data(), pperm.size())) return rc;
     if (int rc = r->upload(&S.lights, d->lights, (size_t)d->n_lights)) return rc;
     S.n_nodes = d->n_nodes;
-    r->has_media = d->n_media != 0;
     r->give_up_lanes = 8;
     r->give_up_segments = 8;
     if (const char *env = std::getenv("V4R_GIVE_UP_LANES")) r->give_up_lanes = (uint32_t)std::max(0, std::min(63, std::atoi(env)));
@@ -1341,19 +1354,31 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     if (r->batch_passes >= 16u) r->batch_passes &= ~15u;  // whole groups of passes for the tiled order of the camera rays
     uint32_t n_pipes = 3;
     if (const char *env = std::getenv("V4R_PIPES")) n_pipes = (uint32_t)std::max(1, std::min(4, std::atoi(env)));
-    r->grid_trace = r->has_media ? std::max(std::max(grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, true, false, false>, n_cu), grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, true, true, false>, n_cu)), grid_for(k_trace_rays<true>, n_cu))
-                                 : std::max(std::max(grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, false, false, false>, n_cu), grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, false, true, false>, n_cu)), grid_for(k_trace_rays<false>, n_cu));
+    auto with_media_mode = [&](auto f) {  // f(std::integral_constant<int, mode>)
+        switch (r->media_mode) {
+            case MEDIA_IN_TREE: return f(std::integral_constant<int, MEDIA_IN_TREE>{});
+            case MEDIA_DIRECT: return f(std::integral_constant<int, MEDIA_DIRECT>{});
+            default: return f(std::integral_constant<int, MEDIA_NONE>{});
+        }
+    };
+    r->grid_trace = with_media_mode([&](auto m) {
+        constexpr int M = decltype(m)::value;
+        return std::max(std::max(grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, M, false, false>, n_cu), grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, M, true, false>, n_cu)),
+                        grid_for(k_trace_rays<M>, n_cu));
+    });
     r->grid_shade = (uint32_t)n_cu * 8u;
     r->grid_stream = (uint32_t)n_cu * 8u;
     for (bool noise : r->class_noise) r->any_noise = r->any_noise || noise;
     {
-        uint32_t g = r->has_media ? (r->any_noise ? grid_for(k_tail<false, true, true>, n_cu) : grid_for(k_tail<false, true, false>, n_cu))
-                                  : (r->any_noise ? grid_for(k_tail<false, false, true>, n_cu) : grid_for(k_tail<false, false, false>, n_cu));
+        uint32_t g = with_media_mode([&](auto m) {
+            constexpr int M = decltype(m)::value;
+            return r->any_noise ? grid_for(k_tail<false, M, true>, n_cu) : grid_for(k_tail<false, M, false>, n_cu);
+        });
         r->grid_tail = std::min(g, r->grid_trace);  // the stack spill slab has one column per thread of a trace launch
     }
     // measured: +2 % (spheres) to +5 % (bunny) with the tail from segment 12; the variants that carry the medium or the
     // Perlin code (3 waves/SIMD) only pay off later (C1 +1.5 % from 24, -3 % from 12)
-    r->tail_segment = r->has_media || r->any_noise ? 24 : 12;
+    r->tail_segment = r->media_mode == MEDIA_IN_TREE || r->any_noise ? 24 : 12;
     if (const char *env = std::getenv("V4R_TAIL_SEGMENT")) r->tail_segment = (uint32_t)std::max(0, std::atoi(env));
     // a ray's stack holds at most three entries per level of the wide tree above its current node
     uint32_t stack_max = 3u * wide_depth + 1u;
@@ -1383,35 +1408,32 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     return V4R_OK;
 }
 
-void launch_trace(v4r_renderer *r, Pipe &pipe, uint32_t seg, const PrimaryArgs &A) {
+// Instantiations of k_trace: work counters x media mode x (segment 0 generates its camera rays) x (second launch).
+template <bool COUNT, int MEDIA, bool PRIMARY>
+void launch_trace_as(v4r_renderer *r, Pipe &pipe, uint32_t seg, const PrimaryArgs &A) {
     dim3 grid(r->grid_trace), block(BLOCK);
     constexpr int R = TRACE_RAYS_PER_THREAD;
-    // instantiations: work counters x constant media x (segment 0 generates its camera rays)
-    int which = (r->counting ? 4 : 0) | (r->has_media ? 2 : 0) | (seg == 0 ? 1 : 0);
     // the first segments hold nearly all rays: there a wave gives its last few rays up to a second launch
     uint32_t give_up = seg < r->give_up_segments ? r->give_up_lanes : 0u;
-    auto launch = [&](auto kernel, uint32_t lanes) { hipLaunchKernelGGL(kernel, grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A, lanes); };
-    switch (which) {
-        case 0: launch(k_trace<false, R, false, false, false>, give_up); break;
-        case 1: launch(k_trace<false, R, false, true, false>, give_up); break;
-        case 2: launch(k_trace<false, R, true, false, false>, give_up); break;
-        case 3: launch(k_trace<false, R, true, true, false>, give_up); break;
-        case 4: launch(k_trace<true, R, false, false, false>, give_up); break;
-        case 5: launch(k_trace<true, R, false, true, false>, give_up); break;
-        case 6: launch(k_trace<true, R, true, false, false>, give_up); break;
-        default: launch(k_trace<true, R, true, true, false>, give_up); break;
+    hipLaunchKernelGGL((k_trace<COUNT, R, MEDIA, PRIMARY, false>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A, give_up);
+    if (give_up) hipLaunchKernelGGL((k_trace<COUNT, R, MEDIA, PRIMARY, true>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A, 0u);
+}
+template <bool COUNT, int MEDIA>
+void launch_trace_media(v4r_renderer *r, Pipe &pipe, uint32_t seg, const PrimaryArgs &A) {
+    if (seg == 0) launch_trace_as<COUNT, MEDIA, true>(r, pipe, seg, A);
+    else launch_trace_as<COUNT, MEDIA, false>(r, pipe, seg, A);
+}
+template <bool COUNT>
+void launch_trace_counting(v4r_renderer *r, Pipe &pipe, uint32_t seg, const PrimaryArgs &A) {
+    switch (r->media_mode) {
+        case MEDIA_IN_TREE: launch_trace_media<COUNT, MEDIA_IN_TREE>(r, pipe, seg, A); break;
+        case MEDIA_DIRECT: launch_trace_media<COUNT, MEDIA_DIRECT>(r, pipe, seg, A); break;
+        default: launch_trace_media<COUNT, MEDIA_NONE>(r, pipe, seg, A); break;
     }
-    if (!give_up) return;
-    switch (which) {
-        case 0: launch(k_trace<false, R, false, false, true>, 0u); break;
-        case 1: launch(k_trace<false, R, false, true, true>, 0u); break;
-        case 2: launch(k_trace<false, R, true, false, true>, 0u); break;
-        case 3: launch(k_trace<false, R, true, true, true>, 0u); break;
-        case 4: launch(k_trace<true, R, false, false, true>, 0u); break;
-        case 5: launch(k_trace<true, R, false, true, true>, 0u); break;
-        case 6: launch(k_trace<true, R, true, false, true>, 0u); break;
-        default: launch(k_trace<true, R, true, true, true>, 0u); break;
-    }
+}
+void launch_trace(v4r_renderer *r, Pipe &pipe, uint32_t seg, const PrimaryArgs &A) {
+    if (r->counting) launch_trace_counting<true>(r, pipe, seg, A);
+    else launch_trace_counting<false>(r, pipe, seg, A);
 }
 
 template <int CLS>
@@ -1429,19 +1451,23 @@ void launch_shade(v4r_renderer *r, Pipe &pipe, uint32_t seg) {
     }
 }
 
-void launch_tail(v4r_renderer *r, Pipe &pipe, uint32_t seg) {
+template <bool COUNT, int MEDIA>
+void launch_tail_as(v4r_renderer *r, Pipe &pipe, uint32_t seg) {
     dim3 grid(r->grid_tail), block(BLOCK);
-    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, block, 0, pipe.stream, r->S, pipe.Q, seg); };
-    switch ((r->counting ? 4 : 0) | (r->has_media ? 2 : 0) | (r->any_noise ? 1 : 0)) {
-        case 0: launch(k_tail<false, false, false>); break;
-        case 1: launch(k_tail<false, false, true>); break;
-        case 2: launch(k_tail<false, true, false>); break;
-        case 3: launch(k_tail<false, true, true>); break;
-        case 4: launch(k_tail<true, false, false>); break;
-        case 5: launch(k_tail<true, false, true>); break;
-        case 6: launch(k_tail<true, true, false>); break;
-        default: launch(k_tail<true, true, true>); break;
+    if (r->any_noise) hipLaunchKernelGGL((k_tail<COUNT, MEDIA, true>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg);
+    else hipLaunchKernelGGL((k_tail<COUNT, MEDIA, false>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg);
+}
+template <bool COUNT>
+void launch_tail_counting(v4r_renderer *r, Pipe &pipe, uint32_t seg) {
+    switch (r->media_mode) {
+        case MEDIA_IN_TREE: launch_tail_as<COUNT, MEDIA_IN_TREE>(r, pipe, seg); break;
+        case MEDIA_DIRECT: launch_tail_as<COUNT, MEDIA_DIRECT>(r, pipe, seg); break;
+        default: launch_tail_as<COUNT, MEDIA_NONE>(r, pipe, seg); break;
     }
+}
+void launch_tail(v4r_renderer *r, Pipe &pipe, uint32_t seg) {
+    if (r->counting) launch_tail_counting<true>(r, pipe, seg);
+    else launch_tail_counting<false>(r, pipe, seg);
 }
 
 int run_batch(v4r_renderer *r, Pipe &pipe, uint64_t seed, uint32_t first_pass, uint32_t pass_stride, uint32_t n_batch_passes, uint32_t row0,
@@ -1699,12 +1725,15 @@ static int trace_common(v4r_renderer *r, uint32_t n, const float *host_origin, c
     if (e == hipSuccess) e = hipMalloc((void **)&d_t, (size_t)n * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&d_p, (size_t)n * sizeof(uint32_t));
     if (e == hipSuccess) {
-        if (r->has_media)
-            hipLaunchKernelGGL(k_trace_rays<true>, dim3(r->grid_trace), dim3(BLOCK), 0, r->stream, r->S, r->pipes[0].Q, n, d_o, d_d,
-                               (uint32_t)seed, (uint32_t)(seed >> 32), d_p, d_t);
-        else
-            hipLaunchKernelGGL(k_trace_rays<false>, dim3(r->grid_trace), dim3(BLOCK), 0, r->stream, r->S, r->pipes[0].Q, n, d_o, d_d,
-                               (uint32_t)seed, (uint32_t)(seed >> 32), d_p, d_t);
+        auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3(r->grid_trace), dim3(BLOCK), 0, r->stream, r->S, r->pipes[0].Q, n, d_o, d_d, (uint32_t)seed,
+                               (uint32_t)(seed >> 32), d_p, d_t);
+        };
+        switch (r->media_mode) {
+            case MEDIA_IN_TREE: launch(k_trace_rays<MEDIA_IN_TREE>); break;
+            case MEDIA_DIRECT: launch(k_trace_rays<MEDIA_DIRECT>); break;
+            default: launch(k_trace_rays<MEDIA_NONE>); break;
+        }
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(r->stream);

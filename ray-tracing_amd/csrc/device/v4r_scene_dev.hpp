@@ -20,6 +20,7 @@ enum {
 };
 
 constexpr uint32_t NO_PRIM = 0xFFFFFFFFu;
+constexpr size_t MAX_DIRECT_MEDIA = 4;  // each costs every ray about a sixth of an average traversal
 
 struct SceneDev {
     const float4 *nodes4;        // 8 x float4 per 4-wide node (wide_step)
@@ -38,6 +39,8 @@ struct SceneDev {
     const uint8_t *perlin_perm;  // 768 bytes per table: perm_x, perm_y, perm_z
     const uint32_t *lights;      // primitive indices
     uint32_t n_nodes, n_prims, n_lights, flags;
+    const uint32_t *media_direct;  // primitives (constant media) tested before the tree instead of inside it
+    uint32_t n_media_direct;
     uint32_t n_top_nodes;        // the first n_top_nodes wide nodes are the top levels of the tree (breadth first): k_trace keeps them in LDS
     float bg[3], env[3];
     v4r_camera cam;
@@ -416,14 +419,27 @@ V4R_DEV void wide_leaves(const SceneDev &S, V3 o, V3 d, Stack &st, Best &best, W
 // has made a few steps), those lanes give their rays up and the function returns true for them, with
 // the closest hit found so far in `best`: the caller queues such rays for a second launch in which
 // they sit next to each other instead of holding a nearly empty wave.  0 = never give up.
-template <bool COUNT, bool MEDIA, class KeyFn>
+// MEDIA: how the scene's constant media are met -- MEDIA_NONE: the scene has none; MEDIA_IN_TREE: they are leaves of
+// the tree (wide_step / consider carry the medium code and the never-cull rule); MEDIA_DIRECT: see below.
+enum : int { MEDIA_NONE = 0, MEDIA_IN_TREE = 1, MEDIA_DIRECT = 2 };
+template <bool COUNT, int MEDIA, class KeyFn>
 V4R_DEV bool traverse(const SceneDev &S, V3 o, V3 d, bool active, Stack &st, Best &best, TraceCounters &cnt, KeyFn key,
-                      uint32_t give_up_lanes) {
+                      uint32_t give_up_lanes, bool resumed = false) {
     if (S.n_prims == 0) return false;
+    // Scenes with a few constant media: the media are not in the tree; every ray tests them first (the closest-hit
+    // rule does not depend on the order), and the traversal runs without the medium code and without subtrees that
+    // must not be culled.  A ray that resumes (second trace launch) carries those hits in `best` already.
+    if (MEDIA == MEDIA_DIRECT && !resumed) {
+        for (uint32_t k = 0; k < S.n_media_direct; ++k)
+            if (active) {
+                if (COUNT) cnt.prims++;
+                consider<true>(S, S.media_direct[k], o, d, best, key);
+            }
+    }
     if (S.n_nodes == 0) {  // single shape: tested without any box (bvh.rs:218-224)
         if (active) {
             if (COUNT) cnt.prims++;
-            consider<MEDIA>(S, 0, o, d, best, key);
+            consider<MEDIA == MEDIA_IN_TREE>(S, 0, o, d, best, key);
         }
         return false;
     }
@@ -442,9 +458,9 @@ V4R_DEV bool traverse(const SceneDev &S, V3 o, V3 d, bool active, Stack &st, Bes
             if (m_parked != 0ull && __popcll(m_parked) * V4R_VOTE_DEN >= (__popcll(m_parked) + __popcll(m_step)) * V4R_VOTE_NUM) break;
             if (COUNT) cnt.wave_steps++;
             ++steps;
-            if (W.stepping()) wide_step<COUNT, MEDIA>(S, o, inv, st, best, W, cnt);
+            if (W.stepping()) wide_step<COUNT, MEDIA == MEDIA_IN_TREE>(S, o, inv, st, best, W, cnt);
         }
-        if (__ballot(W.parked()) != 0ull) wide_leaves<COUNT, MEDIA>(S, o, d, st, best, W, cnt, key);
+        if (__ballot(W.parked()) != 0ull) wide_leaves<COUNT, MEDIA == MEDIA_IN_TREE>(S, o, d, st, best, W, cnt, key);
         if (__ballot(W.cur != TRAV_NONE) == 0ull) break;
     }
     return false;

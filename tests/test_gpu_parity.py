@@ -385,6 +385,40 @@ def test_batching_knobs_change_nothing(monkeypatch):
             monkeypatch.delenv(k)
 
 
+def test_media_tested_before_the_tree_change_nothing():
+    """Scenes with at most four constant media test them before the traversal, with a tree built over the other
+    primitives; with the host's tree kept (V4R_FLAG_KEEP_HOST_BVH) the media stay leaves of the tree and the
+    traversal carries the medium code.  The closest-hit rule does not depend on the order: same hits, bit-identical
+    image.  With five media or more they always stay in the tree (the last case)."""
+    cam = PerspectiveCameraParam((0, 0, -30), (0, 0, 0), 50.0)
+    cases = [("c1", None)]
+    for seed in (11, 12, 13, 14):
+        cases.append((seed, 8))     # 2-4 media
+    cases.append((13, 14))          # 6 media
+    n_direct = 0
+    for what, n_shapes in cases:
+        results = []
+        for flags in (0, _abi.V4R_FLAG_KEEP_HOST_BVH):
+            if n_shapes is None:
+                scene, r = make(what, flags=flags)
+            else:
+                scene = random_scene(what, n_shapes)
+                scene.set_options(False, flags)
+                r = Renderer(RendererParam(96, 64, max_depth=12), cam, scene)
+            d = r.desc.contents
+            n_media = int(sum(1 for i in range(d.n_prims) if (d.prims[i].type & 0xFF) == _abi.V4R_PRIM_MEDIUM))
+            prim, t = r.trace_primary()
+            r.render_passes(6)
+            img, _ = r.read_accumulator()
+            results.append((prim, t, img))
+            r.close()
+        n_direct += 1 <= n_media <= 4
+        assert np.array_equal(results[0][0], results[1][0]), what
+        assert np.array_equal(results[0][1], results[1][1]), what
+        assert np.array_equal(results[0][2], results[1][2], equal_nan=True), what
+    assert n_direct >= 5   # c1 and the 8-shape scenes are meant to take the direct path
+
+
 def test_row_bands_add_up_to_the_full_image():
     """Tile split: bands of rows rendered separately (any heights, any order) are exactly the rows of the
     full-image render, because a pixel's random streams are keyed by its position in the whole image."""
