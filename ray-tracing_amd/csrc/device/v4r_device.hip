@@ -496,8 +496,11 @@ V4R_DEV bool shade_hit(const SceneDev &S, const PathState &p, float4 dcol, uint3
 }
 
 // Shading of the hits of one material class of one segment.
+#ifndef V4R_SHADE_MIN_WAVES_NOISE
+#define V4R_SHADE_MIN_WAVES_NOISE 4  // the Lambertian kernels with the Perlin code need 129 VGPRs unforced
+#endif
 template <int CLS, bool COUNT, bool NOISE>
-__global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, Queues Q, uint32_t seg) {
+__global__ __launch_bounds__(BLOCK, NOISE ? V4R_SHADE_MIN_WAVES_NOISE : 1) void k_shade(SceneDev S, Queues Q, uint32_t seg) {
     SegCtr *ctr = Q.ctr + seg;
     const uint32_t n_in = ctr->hit_count[CLS];
     const uint32_t *hq = Q.hit[CLS];

@@ -554,18 +554,25 @@ V4R_DEV float perlin_noise(const float4 *vec, const uint8_t *perm, V3 p) {
     float uu = u * u * (3.0f - u * 2.0f);
     float vv = v * v * (3.0f - v * 2.0f);
     float ww = w * w * (3.0f - w * 2.0f);
+    // The eight lattice corners in the reference's order (di, dj, dk), two at a time (dk = 0, 1) with packed f32
+    // multiplies and adds: every product and sum is the one of the scalar form, rounded alike, and the eight terms
+    // are added to `accum` in the same order.
+    typedef float pair __attribute__((ext_vector_type(2)));
+    const pair dw = {w, w - 1.0f}, wk = {1.0f - ww, ww};
     float accum = 0.0f;
 #pragma unroll
     for (int di = 0; di < 2; ++di)
 #pragma unroll
-        for (int dj = 0; dj < 2; ++dj)
-#pragma unroll
-            for (int dk = 0; dk < 2; ++dk) {
-                uint32_t idx = perm[(i + di) & 255u] ^ perm[256 + ((j + dj) & 255u)] ^ perm[512 + ((k + dk) & 255u)];
-                float4 c = vec[idx];
-                float d = c.x * (u - (float)di) + c.y * (v - (float)dj) + c.z * (w - (float)dk);
-                accum += (di ? uu : 1.0f - uu) * (dj ? vv : 1.0f - vv) * (dk ? ww : 1.0f - ww) * d;
-            }
+        for (int dj = 0; dj < 2; ++dj) {
+            uint32_t base = perm[(i + di) & 255u] ^ perm[256 + ((j + dj) & 255u)];
+            float4 c0 = vec[base ^ perm[512 + (k & 255u)]], c1 = vec[base ^ perm[512 + ((k + 1u) & 255u)]];
+            float du = u - (float)di, dv = v - (float)dj;
+            pair d = (pair{c0.x, c1.x} * du + pair{c0.y, c1.y} * dv) + pair{c0.z, c1.z} * dw;
+            float wij = (di ? uu : 1.0f - uu) * (dj ? vv : 1.0f - vv);
+            pair term = (wk * wij) * d;
+            accum += term.x;
+            accum += term.y;
+        }
     return accum;
 }
 
