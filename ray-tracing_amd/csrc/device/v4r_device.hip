@@ -772,6 +772,7 @@ struct v4r_renderer {
     int media_mode = MEDIA_NONE;  // selects the kernel instantiations (see traverse)
     bool class_noise[CLS_COUNT] = {false, false, false, false, false, false};  // a material of the class uses a noise texture
     uint32_t give_up_lanes = 0, give_up_segments = 0;  // see k_trace
+    uint32_t tile_passes_log2 = 4;  // passes per wave tile of the camera-ray order (see ray_order)
     size_t ctr_bytes = 0;
     uint32_t max_depth = 0, spill_depth = 0;
 
@@ -1333,6 +1334,7 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     r->give_up_lanes = 8;
     r->give_up_segments = 8;
     if (const char *env = std::getenv("V4R_GIVE_UP_LANES")) r->give_up_lanes = (uint32_t)std::max(0, std::min(63, std::atoi(env)));
+    if (const char *env = std::getenv("V4R_TILE_PASSES_LOG2")) r->tile_passes_log2 = (uint32_t)std::min(6, std::max(0, std::atoi(env)));
     if (const char *env = std::getenv("V4R_GIVE_UP_SEGMENTS")) r->give_up_segments = (uint32_t)std::max(0, std::atoi(env));
     S.n_prims = d->n_prims;
     S.n_lights = d->n_lights;
@@ -1480,9 +1482,8 @@ int run_batch(v4r_renderer *r, Pipe &pipe, uint64_t seed, uint32_t first_pass, u
     HIP_TRY(hipMemsetAsync(pipe.Q.ctr, 0, r->ctr_bytes, pipe.stream));
     RayOrder order;
     {
-        static const int lp_max = getenv("V4R_TILE_PASSES_LOG2") ? std::min(6, std::max(0, atoi(getenv("V4R_TILE_PASSES_LOG2")))) : 4;
         uint32_t lp = 0;
-        while ((int)lp < lp_max && (2u << lp) <= n_batch_passes) ++lp;
+        while (lp < r->tile_passes_log2 && (2u << lp) <= n_batch_passes) ++lp;
         order.lp = lp;
         order.tw_log = (6u - lp + 1u) / 2u;
         order.th_log = (6u - lp) / 2u;
