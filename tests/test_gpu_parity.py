@@ -208,6 +208,46 @@ def test_random_scenes_match_oracle(seed, n_shapes):
     r.close()
 
 
+def _degenerate_scenes():
+    white = Lambertian(SolidColor((0.8, 0.8, 0.8)))
+    fog = Isotropic(SolidColor((0.9, 0.9, 0.9)))
+    empty = Scene((0.3, 0.5, 0.9))
+    one = Scene((0.3, 0.5, 0.9))
+    one.add(Sphere((0, 0, 0), 2.0), Metal((0.9, 0.8, 0.7), 0.1))
+    only_fog = Scene((0.3, 0.5, 0.9))
+    only_fog.add(ConstantMedium(Sphere((0, 0, 0), 3.0), 0.6), fog)
+    fog_and_one = Scene((0.3, 0.5, 0.9))            # one non-medium primitive: the media stay in the tree
+    fog_and_one.add(ConstantMedium(Sphere((0, 0, 0), 3.0), 0.6), fog)
+    fog_and_one.add(ConstantMedium(Cuboid((-4, -4, -1), (-1, 4, 1)), 1.5), fog)
+    fog_and_one.add(Sphere((1, 0, 0), 1.0), white)
+    fog_and_two = Scene((0.3, 0.5, 0.9))            # the media are tested before the tree
+    fog_and_two.add(Sphere((1, 0, 0), 1.0), white)
+    fog_and_two.add(ConstantMedium(Sphere((0, 0, 0), 3.0), 0.6), fog)
+    fog_and_two.add(XYRect(-5, 5, -5, 5, 4.0), DiffuseLight(SolidColor((3, 3, 3))), True)
+    return {"empty": empty, "one sphere": one, "only fog": only_fog, "two fogs and a sphere": fog_and_one, "fog, sphere, light": fog_and_two}
+
+
+@pytest.mark.parametrize("size", [(1, 1), (3, 5), (64, 48)])
+def test_degenerate_scenes_match_oracle(size):
+    """No primitive, one primitive (no tree), media only, media in the tree and beside it; images of one pixel and
+    of sizes no tile divides."""
+    cam = PerspectiveCameraParam((0, 1, -12), (0, 0, 0), 40.0)
+    for what, scene in _degenerate_scenes().items():
+        r = Renderer(RendererParam(size[0], size[1], max_depth=10), cam, scene)
+        prim_d, t_d = r.trace_primary()
+        prim_o, t_o = oracle.trace_primary(r.desc)
+        assert np.array_equal(prim_d, prim_o), what
+        hit = prim_o != MISS
+        assert np.allclose(t_d[hit], t_o[hit], rtol=1e-5, atol=0), what
+        r.render_passes(5)
+        img_d, n = r.read_accumulator()
+        img_o, _ = oracle.render(r.desc, 5, seed=r.seed)
+        assert n == 5 and np.isfinite(img_d).all(), what
+        close = np.abs(img_d - img_o).max(axis=2) <= 2e-3 * (np.abs(img_o).max(axis=2) + 0.05)
+        assert close.mean() >= 0.97, (what, float(close.mean()))
+        r.close()
+
+
 def test_furnace_is_exact():
     """One convex Lambertian sphere, no lights, background B: every scattered ray escapes, so a hit pixel is
     exactly albedo * B and a miss pixel exactly B (renderer.rs:184,245-255,299-318)."""
