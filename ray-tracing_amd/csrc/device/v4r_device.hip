@@ -638,6 +638,12 @@ __global__ __launch_bounds__(BLOCK, NOISE ? V4R_TAIL_MIN_WAVES_NOISE : 1) void k
     }
 }
 
+// max_depth = 0 (renderer.rs:128-130): ray_color returns `environment` before it traces anything.
+__global__ __launch_bounds__(BLOCK) void k_fill_rad(Queues Q, uint32_t n, float r, float g, float b) {
+    uint32_t stride = gridDim.x * BLOCK;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) Q.rad[i] = make_float4(r, g, b, 0.0f);
+}
+
 // RenderResult::add (renderer.rs:355-368) for a whole batch: accum[pixel] += sum over the batch's
 // passes, in ascending pass order.
 __global__ __launch_bounds__(BLOCK) void k_resolve(Queues Q, float *accum, uint32_t npix, uint32_t n_batch_passes) {
@@ -1522,6 +1528,8 @@ int run_batch(v4r_renderer *r, Pipe &pipe, uint64_t seed, uint32_t first_pass, u
         launch_shade<CLS_DIELECTRIC>(r, pipe, seg);
         launch_shade<CLS_ISOTROPIC>(r, pipe, seg);
     }
+    if (r->S.max_depth == 0)
+        hipLaunchKernelGGL(k_fill_rad, dim3(r->grid_stream), dim3(BLOCK), 0, pipe.stream, pipe.Q, n_paths, r->S.env[0], r->S.env[1], r->S.env[2]);
     // accumulate in batch order: this batch's k_resolve runs after the previous batch's
     if (r->last_resolve && r->last_resolve != pipe.done) HIP_TRY(hipStreamWaitEvent(pipe.stream, r->last_resolve, 0));
     hipLaunchKernelGGL(k_resolve, dim3(r->grid_stream), dim3(BLOCK), 0, pipe.stream, pipe.Q, r->accum + 3 * (size_t)band_offset, band_pix,

@@ -277,6 +277,13 @@ def test_depth_budget_returns_environment():
     assert (img[prim == 0] == np.float32([1.0, 1.5, 2.0])).all()
     assert (img[prim == MISS] == np.float32(0.25)).all()
     r.close()
+    # max_depth = 0: ray_color returns `environment` before tracing anything (renderer.rs:128-130)
+    r = Renderer(RendererParam(32, 32, max_depth=0, antialias=False), PerspectiveCameraParam((0, 0, 4), (0, 0, 0), 40.0), scene)
+    r.render_passes(3)
+    img, n = r.read_accumulator()
+    img_o, _ = oracle.render(r.desc, 3, seed=r.seed)
+    assert n == 3 and (img == np.float32([6.0, 9.0, 12.0])).all() and np.array_equal(img, img_o)
+    r.close()
 
 
 def test_batches_and_single_passes_are_bit_identical():
