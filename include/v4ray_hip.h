@@ -8,7 +8,10 @@
  *
  * Every function returns 0 (V4R_OK) or a negative V4R_E_* code and never aborts the process;
  * `v4r_last_error()` returns a thread-local description of the last failure.  Calls on one
- * renderer handle are serialised on that handle's HIP stream; different handles are independent.
+ * renderer handle may come from several threads: each entry point holds the handle's lock for its
+ * whole call and queues its device work on the handle's HIP stream (a sequence such as clear +
+ * render + read that must not interleave with another thread's is the caller's to bracket);
+ * different handles are independent.
  *
  * Each declaration cites the reference interface (file:line under the reference tree) it replaces.
  */

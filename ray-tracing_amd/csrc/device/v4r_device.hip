@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <utility>
@@ -752,6 +753,7 @@ struct Pipe {
 };
 
 struct v4r_renderer {
+    std::recursive_mutex mu;  // host-side state of the handle: every entry point holds it for its whole call
     int device = 0;
     hipStream_t stream = nullptr;  // public stream = pipeline 0's
     SceneDev S{};
@@ -1606,6 +1608,7 @@ void v4r_renderer_destroy(v4r_renderer *r) {
 int v4r_render_rows(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_t pass_stride, uint32_t n_passes, uint32_t row0,
                     uint32_t n_rows) {
     if (!r) return set_error(V4R_E_INVALID, "NULL renderer");
+    std::lock_guard<std::recursive_mutex> hold(r->mu);
     if (n_rows == 0 || row0 >= r->S.height || n_rows > r->S.height - row0) return set_error(V4R_E_INVALID, "row band outside the image");
     if (pass_stride == 0) pass_stride = 1;
     HIP_TRY(hipSetDevice(r->device));
@@ -1645,6 +1648,7 @@ int v4r_render(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_t pas
 
 int v4r_accum_bind(v4r_renderer *r, float *device_hwc) {
     if (!r) return set_error(V4R_E_INVALID, "NULL renderer");
+    std::lock_guard<std::recursive_mutex> hold(r->mu);
     HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(hipStreamSynchronize(r->stream));
     r->accum = device_hwc ? device_hwc : r->accum_own;
@@ -1653,6 +1657,7 @@ int v4r_accum_bind(v4r_renderer *r, float *device_hwc) {
 
 int v4r_reduce(v4r_renderer *r, void *rccl_comm, int root) {
     if (!r || !rccl_comm) return set_error(V4R_E_INVALID, "NULL argument");
+    std::lock_guard<std::recursive_mutex> hold(r->mu);
     // ncclResult_t ncclReduce(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t)
     using reduce_fn = int (*)(const void *, void *, size_t, int, int, int, void *, hipStream_t);
     static reduce_fn reduce = [] {
@@ -1671,6 +1676,7 @@ int v4r_reduce(v4r_renderer *r, void *rccl_comm, int root) {
 
 int v4r_accum_clear(v4r_renderer *r) {
     if (!r) return set_error(V4R_E_INVALID, "NULL renderer");
+    std::lock_guard<std::recursive_mutex> hold(r->mu);
     HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(hipMemsetAsync(r->accum, 0, (size_t)r->npix * 3 * sizeof(float), r->stream));
     r->n_passes = 0;
@@ -1679,6 +1685,7 @@ int v4r_accum_clear(v4r_renderer *r) {
 
 int v4r_accum_read(v4r_renderer *r, float *host_hwc, uint32_t *n_passes) {
     if (!r) return set_error(V4R_E_INVALID, "NULL renderer");
+    std::lock_guard<std::recursive_mutex> hold(r->mu);
     HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(hipStreamSynchronize(r->stream));
     if (host_hwc) HIP_TRY(hipMemcpy(host_hwc, r->accum, (size_t)r->npix * 3 * sizeof(float), hipMemcpyDeviceToHost));
@@ -1688,6 +1695,7 @@ int v4r_accum_read(v4r_renderer *r, float *host_hwc, uint32_t *n_passes) {
 
 int v4r_accum_write(v4r_renderer *r, const float *host_hwc, uint32_t n_passes) {
     if (!r || !host_hwc) return set_error(V4R_E_INVALID, "NULL argument");
+    std::lock_guard<std::recursive_mutex> hold(r->mu);
     HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(hipStreamSynchronize(r->stream));
     HIP_TRY(hipMemcpyAsync(r->accum, host_hwc, (size_t)r->npix * 3 * sizeof(float), hipMemcpyHostToDevice, r->stream));
@@ -1698,6 +1706,7 @@ int v4r_accum_write(v4r_renderer *r, const float *host_hwc, uint32_t n_passes) {
 
 int v4r_accum_device(v4r_renderer *r, float **device_hwc, uint64_t *n_floats) {
     if (!r) return set_error(V4R_E_INVALID, "NULL renderer");
+    std::lock_guard<std::recursive_mutex> hold(r->mu);
     if (device_hwc) *device_hwc = r->accum;
     if (n_floats) *n_floats = (uint64_t)r->npix * 3;
     return V4R_OK;
@@ -1705,6 +1714,7 @@ int v4r_accum_device(v4r_renderer *r, float **device_hwc, uint64_t *n_floats) {
 
 int v4r_tonemap_u8(v4r_renderer *r, uint32_t n_passes, uint8_t *host_rgb) {
     if (!r || !host_rgb) return set_error(V4R_E_INVALID, "NULL argument");
+    std::lock_guard<std::recursive_mutex> hold(r->mu);
     if (n_passes == 0) return set_error(V4R_E_INVALID, "no passes to average");
     HIP_TRY(hipSetDevice(r->device));
     size_t n = (size_t)r->npix * 3;
@@ -1717,6 +1727,7 @@ int v4r_tonemap_u8(v4r_renderer *r, uint32_t n_passes, uint8_t *host_rgb) {
 
 static int trace_common(v4r_renderer *r, uint32_t n, const float *host_origin, const float *host_dir, uint64_t seed, uint32_t *host_prim_id,
                         float *host_t) {
+    std::lock_guard<std::recursive_mutex> hold(r->mu);
     HIP_TRY(hipSetDevice(r->device));
     if (n == 0) return V4R_OK;
     float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr;
@@ -1770,12 +1781,14 @@ int v4r_trace_rays(v4r_renderer *r, uint32_t n, const float *host_origin, const 
 
 int v4r_stats_enable(v4r_renderer *r, int on) {
     if (!r) return set_error(V4R_E_INVALID, "NULL renderer");
+    std::lock_guard<std::recursive_mutex> hold(r->mu);
     r->counting = on != 0;
     return V4R_OK;
 }
 
 int v4r_stats_read(v4r_renderer *r, v4r_stats *out, int reset) {
     if (!r || !out) return set_error(V4R_E_INVALID, "NULL argument");
+    std::lock_guard<std::recursive_mutex> hold(r->mu);
     HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(hipStreamSynchronize(r->stream));
     unsigned long long h[8];
@@ -1809,6 +1822,7 @@ static int profile_collect(v4r_renderer *r) {
 
 int v4r_profile_enable(v4r_renderer *r, int on) {
     if (!r) return set_error(V4R_E_INVALID, "NULL renderer");
+    std::lock_guard<std::recursive_mutex> hold(r->mu);
     HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(hipStreamSynchronize(r->stream));
     if (int rc = profile_collect(r)) return rc;
@@ -1818,6 +1832,7 @@ int v4r_profile_enable(v4r_renderer *r, int on) {
 
 int v4r_profile_read(v4r_renderer *r, double *trace_ms, uint64_t *trace_launches, int reset) {
     if (!r) return set_error(V4R_E_INVALID, "NULL renderer");
+    std::lock_guard<std::recursive_mutex> hold(r->mu);
     HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(hipStreamSynchronize(r->stream));
     if (int rc = profile_collect(r)) return rc;
@@ -1832,6 +1847,7 @@ int v4r_profile_read(v4r_renderer *r, double *trace_ms, uint64_t *trace_launches
 
 int v4r_synchronize(v4r_renderer *r) {
     if (!r) return set_error(V4R_E_INVALID, "NULL renderer");
+    std::lock_guard<std::recursive_mutex> hold(r->mu);
     HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(hipStreamSynchronize(r->stream));
     return V4R_OK;
@@ -1839,12 +1855,14 @@ int v4r_synchronize(v4r_renderer *r) {
 
 int v4r_stream(v4r_renderer *r, void **hip_stream) {
     if (!r || !hip_stream) return set_error(V4R_E_INVALID, "NULL argument");
+    std::lock_guard<std::recursive_mutex> hold(r->mu);
     *hip_stream = (void *)r->stream;
     return V4R_OK;
 }
 
 int v4r_pass_count(v4r_renderer *r, uint32_t *n_passes) {
     if (!r || !n_passes) return set_error(V4R_E_INVALID, "NULL argument");
+    std::lock_guard<std::recursive_mutex> hold(r->mu);
     *n_passes = r->n_passes;
     return V4R_OK;
 }

@@ -10,6 +10,7 @@ triangles, cuboids, meshes, constant media, diffuse lights, isotropic, image and
 available here too.  All rendering runs in libv4ray_hip.so; nothing falls back to the CPU.
 """
 import asyncio
+import threading
 import ctypes as C
 import os
 from typing import Optional, Sequence, Tuple
@@ -487,6 +488,7 @@ class Renderer:
         self.width, self.height = param.width, param.height
         self.seed = int(seed)
         self._next_pass = 0
+        self._lock = threading.Lock()  # render() may run on several executor threads at once (main.py:1986-1990)
         self._desc = scene.flatten(param, camera)
         lib = device_lib()
         h = C.c_void_p()
@@ -512,12 +514,13 @@ class Renderer:
     def render_pass(self, pass_index: Optional[int] = None) -> np.ndarray:
         """One 1-spp pass (Renderer::render, src/renderer.rs:321-332) as (H, W, 3) float32."""
         lib = device_lib()
-        if pass_index is None:
-            pass_index = self._next_pass
-            self._next_pass += 1
-        check_dev(lib.v4r_accum_clear(self._h))
-        check_dev(lib.v4r_render(self._h, self.seed, int(pass_index), 1, 1))
-        return self.read_accumulator()[0]
+        with self._lock:  # clear + render + read is one unit: concurrent callers take turns, like the RwLock of renderer.rs:359
+            if pass_index is None:
+                pass_index = self._next_pass
+                self._next_pass += 1
+            check_dev(lib.v4r_accum_clear(self._h))
+            check_dev(lib.v4r_render(self._h, self.seed, int(pass_index), 1, 1))
+            return self.read_accumulator()[0]
 
     async def render(self) -> np.ndarray:
         loop = asyncio.get_running_loop()

@@ -466,6 +466,26 @@ def test_media_tested_before_the_tree_change_nothing():
     assert n_direct >= 5   # c1 and the 8-shape scenes are meant to take the direct path
 
 
+def test_concurrent_render_calls_take_turns():
+    """Renderer::render is re-entrant in the reference (main.rs:46-63, main.py:1986-1990 run several at once): eight
+    `await renderer.render()` in flight on one handle return eight different whole passes, the ones single calls return."""
+    import asyncio
+    scene, r = make("c3")
+    singles = [r.render_pass(k) for k in range(8)]
+
+    async def many():
+        return await asyncio.gather(*[r.render() for _ in range(8)])
+    r._next_pass = 0
+    got = asyncio.run(many())
+    used = set()
+    for img in got:
+        match = [k for k in range(8) if k not in used and np.array_equal(img, singles[k])]
+        assert match, "a concurrent render() returned something that is no single pass"
+        used.add(match[0])
+    assert len(used) == 8
+    r.close()
+
+
 def test_row_bands_add_up_to_the_full_image():
     """Tile split: bands of rows rendered separately (any heights, any order) are exactly the rows of the
     full-image render, because a pixel's random streams are keyed by its position in the whole image."""
