@@ -1,22 +1,37 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mpaths/s of the render-loop hot path on N MI355X GPUs of one node.
 
-Workload (config.workload): by default the Book-1 random-spheres scene (c2) at
-1920x1080, 256 samples per pixel per GPU.  One "step" renders those 256 full-image 1-spp passes on every
-rank (rank r takes passes r, r+N, r+2N, ... of one N*256-spp job, so per-GPU work is fixed: weak scaling)
-and, for N > 1, sums the per-GPU radiance accumulators onto rank 0 with one RCCL reduce over xGMI.
-Scene tables are resident in HBM before the timed region starts; nothing crosses PCIe inside it.
+Workload (config.workload): by default the bunny scene (c4: bunny.obj subdivided to 79 488 triangles + an
+earth-textured sphere in a Cornell box) at 1920x1080, 512 samples per pixel per GPU -- the scene the
+>= 100x GPU/CPU target is stated on.  One "step" renders those 512 full-image 1-spp passes on every rank
+(rank r takes passes r, r+N, r+2N, ... of one N*512-spp job, so per-GPU work is fixed: weak scaling) and, for
+N > 1, sums the per-GPU radiance accumulators onto rank 0 with one RCCL reduce over xGMI, ordered on the
+renderer's own stream.  Scene tables are resident in HBM before the timed region starts; nothing crosses
+PCIe inside it.
 
-    python bench.py --gpus 1 --steps 5 --warmup 1
+    python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (BVH traversal + intersection,
-k_trace) in algorithmic bytes per second against the 8 TB/s HBM peak: its device time comes from HIP
-events recorded around every k_trace launch inside the timed region, the bytes from the work counters of
-an instrumented (untimed) run of the same passes.  `cpu_baseline` is the CPU oracle (the scalar C++
-restatement of the reference's loop, oracle/) timed on this host's cores on a bounded sample of the same
-workload -- a reported baseline, not the optimisation target.
+Rank 0 prints ONE JSON line.
+
+`roofline` prices the dominant kernel group (BVH traversal + intersection: k_trace / k_tail).  After the timed
+region the same renderer renders 64 more passes with every batch on one stream and HIP events around the
+traversal, shading and resolve launches (exclusive kernel times), then the same passes once more with the
+instrumented kernels (exact work counts).  From those:
+  * hbm: the bytes a kernel group must move through HBM (its queue records: rays, hit records, class-queue
+    indices, radiance slots -- counted from the work counters x the record sizes) per launch, over its average
+    launch duration, against the 8 TB/s peak; `traffic` is the HBM bytes per launch that rocprofv3's
+    FETCH_SIZE / WRITE_SIZE counters measured for the same workload (committed under profiles/), scaled to
+    this run's launch count.  The BVH nodes and primitive records a ray touches are table reads served by
+    LDS / L1 / L2 (the tables are <= 15 MB) and are listed apart (`tables`), not priced against HBM.
+  * issue: vector instructions issued (SQ_INSTS_VALU of the committed counter passes, per path) x 2 cycles
+    over the SIMD cycles of the measured kernel time at the 2.4 GHz peak clock, and the lanes active per
+    vector instruction.
+The group's binding resource is named in `bound`; `frac` is the fraction of that resource's peak.
+`cpu_baseline` is the CPU oracle (the scalar C++ restatement of the reference's loop, oracle/) timed on every
+hardware thread this host offers, on a bounded sample of the same workload -- a reported baseline, not the
+optimisation target.
 """
 import argparse
 import json
@@ -27,9 +42,22 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "ray-tracing_amd"))
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
-# Bytes of the traversal kernel per unit of work (the record sizes of its queues and tables):
-RAY_RECORD, HIT_RECORD, NODE, PRIM, RADIANCE = 48, 20, 128, 48, 16
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak
+PEAK_CLOCK_HZ = 2.4e9
+SIMDS = 256 * 4
+VALU_ISSUE_CYCLES = 2       # a wave64 vector instruction occupies its SIMD's issue port for 2 cycles
+# Queue record sizes (bytes): ray record, hit record + class-queue index, radiance slot; table records: wide BVH
+# node, primitive, triangle shading record, texel
+RAY_RECORD, HIT_RECORD, QUEUE_INDEX, RADIANCE, NODE, PRIM, TRI_SHADING, TEXEL = 48, 16, 4, 16, 128, 48, 64, 4
+PROFILE_PASSES = 64
+PMC_SUMMARY = {"c4": "profiles/r02_c4_pmc.json", "c2": "profiles/r02_c2_pmc.json"}
+
+WORKLOADS = {
+    "c1": "data/scene.json verbatim (Cornell walls, 4 968-triangle bunny, fog sphere, 4 985 shapes)",
+    "c2": "Book-1 random-spheres scene (484 spheres, Lambertian/metal/dielectric)",
+    "c3": "Cornell box, cosine + light-list mixture sampling",
+    "c4": "bunny.obj subdivided to 79 488 triangles + earth-textured sphere in a Cornell box",
+    "c5": "zy_scene.json (noise/image-textured spheres in a Cornell box)"}
 
 
 def parse():
@@ -37,57 +65,67 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=0, help="passes per GPU per step (default: the workload's full count)")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-profile", action="store_true", help="do not record HIP events around k_trace")
+    ap.add_argument("--no-profile", action="store_true", help="skip the exclusive-timing and work-counter legs (no roofline)")
     ap.add_argument("--split", default="sample", choices=["sample", "tile"],
                     help="N > 1: rank r renders passes r, r+N, ... of the job (sample) or all passes of its band of rows (tile)")
     ap.add_argument("--c4-subdivide", type=int, default=2, help="midpoint subdivisions of bunny.obj in c4 (2: 79 488 triangles, 0: 4 968)")
-    ap.add_argument("--no-bunny", action="store_true", help="skip the short bunny-scene (c4) measurement added to the c2 line")
+    ap.add_argument("--no-side", action="store_true", help="skip the short random-spheres (c2) measurement added to the c4 line")
     return ap.parse_args()
 
 
-def trace_bytes(stats):
-    """Algorithmic bytes of k_trace for the counted work: one 48-B ray record per segment (read from the queue, or for a
-    camera ray that hits something written to it), 128 B per 4-wide BVH node and 48 B per primitive fetched, per hit a
-    16-B hit record + a 4-B class-queue index, per miss one 16-B radiance write."""
-    hits = stats["shaded"]
-    misses = stats["segments"] - hits
-    return (stats["segments"] * RAY_RECORD + stats["nodes"] * NODE + stats["prims"] * PRIM + hits * HIT_RECORD
-            + misses * RADIANCE)
+def queue_bytes(stats):
+    """Bytes each kernel group must move through HBM for the counted work (queue records only).
+    k_trace: per ray segment one 48-B ray record (read from the queue; a camera ray is generated in registers and
+    written instead), per hit a 16-B hit record + a 4-B class-queue index written, per miss a 16-B radiance slot.
+    k_shade: per hit the index, the ray and the hit record read, then the scattered ray (48 B) or, when the path
+    ends there, its radiance slot (16 B) written.  k_resolve: a 16-B radiance slot read per path, the fp32 RGB
+    accumulator read and written once per pixel and batch."""
+    segs, hits, paths = stats["segments"], stats["shaded"], stats["paths"]
+    misses = segs - hits
+    scattered = segs - paths           # every non-camera segment was written by a shading launch
+    ended_in_shade = hits - scattered   # lights, exhausted depth budgets
+    return {"trace": segs * RAY_RECORD + hits * (HIT_RECORD + QUEUE_INDEX) + misses * RADIANCE,
+            "shade": hits * (QUEUE_INDEX + RAY_RECORD + HIT_RECORD) + scattered * RAY_RECORD + ended_in_shade * RADIANCE,
+            "resolve": paths * RADIANCE}
 
 
 def cpu_baseline(desc, npix, seed):
-    """The oracle on this host's cores, ~10-30 s of CPU work on the same scene at full resolution."""
+    """The oracle on every hardware thread of this host, ~10-30 s of CPU work on the same scene at full resolution."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle  # test infrastructure: used here only as the timed CPU baseline
-    cores = max(1, min(16, os.cpu_count() or 1))
-    oracle.render(desc, 1, seed=seed, threads=cores, pixel_stride=64)  # page in
+    threads = max(1, min(1024, os.cpu_count() or 1))  # src/main.rs:57 spawns num_cpus::get() render tasks
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = threads
+    oracle.render(desc, 1, seed=seed, threads=threads, pixel_stride=64)  # page in, start the threads once
     t0 = time.perf_counter()
-    oracle.render(desc, 1, seed=seed, threads=cores)
+    oracle.render(desc, 1, seed=seed, threads=threads)
     dt = time.perf_counter() - t0
-    passes = max(1, min(16, int(round(1.5 / max(dt, 1e-3)))))  # ~1.5 s of wall time on every core
+    passes = max(1, min(64, int(round(2.0 / max(dt, 1e-3)))))  # ~2 s of wall time on every thread
     if passes > 1:
         t0 = time.perf_counter()
-        oracle.render(desc, passes, seed=seed, threads=cores)
+        oracle.render(desc, passes, seed=seed, threads=threads)
         dt = time.perf_counter() - t0
     # one thread, every 4th pixel of one pass (the rate does not depend on which pixels are sampled)
     t0 = time.perf_counter()
     oracle.render(desc, 1, seed=seed, threads=1, pixel_stride=4)
     one = (npix + 3) // 4 / (time.perf_counter() - t0) / 1e6
-    return {"value": round(npix * passes / dt / 1e6, 4), "unit": "Mpaths/s", "cores": cores, "kind": "port", "value_1_thread": round(one, 4),
-            "sample": f"{passes} full-resolution 1-spp pass(es) of the same scene, {cores} threads, "
+    return {"value": round(npix * passes / dt / 1e6, 4), "unit": "Mpaths/s", "cores": threads, "kind": "port",
+            "host_cpu_count": os.cpu_count(), "host_cpus_usable": usable, "value_1_thread": round(one, 4),
+            "sample": f"{passes} full-resolution 1-spp pass(es) of the same scene, {threads} threads (= os.cpu_count()), "
                       f"reference-order (unordered candidate-set) BVH traversal"}
 
 
-def bunny_scene(Renderer, scenes, device):
-    """The scene the >= 100x GPU/CPU target is stated on (c4: 79 488-triangle bunny, 1080p), measured briefly
-    beside the headline workload: 2 x 128 passes on the GPU, the oracle on the host cores."""
-    w, h, _ = scenes.FULL_SIZE["c4"]
-    scene = scenes.load("c4", w, h, pretransform_triangles=True)
+def side_scene(Renderer, scenes, device, with_cpu):
+    """The random-spheres scene (c2, 1080p) measured briefly beside the headline workload."""
+    w, h, _ = scenes.FULL_SIZE["c2"]
+    scene = scenes.load("c2", w, h)
     r = Renderer(scene.renderer_param, scene.camera_param, scene, device=device)
     spp, steps = 128, 2
     r.render_passes(spp)
@@ -99,11 +137,102 @@ def bunny_scene(Renderer, scenes, device):
     r.synchronize()
     dt = time.perf_counter() - t0
     value = w * h * spp * steps / dt / 1e6
-    cpu = cpu_baseline(r.desc, w * h, r.seed)
+    out = {"workload": "c2: " + WORKLOADS["c2"] + ", 1920x1080", "value": round(value, 3), "unit": "Mpaths/s",
+           "spp_per_step": spp, "steps": steps}
+    if with_cpu:
+        out["cpu_baseline"] = cpu_baseline(r.desc, w * h, r.seed)
+        out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
     r.close()
-    return {"workload": "c4: bunny.obj subdivided to 79 488 triangles + earth-textured sphere in a Cornell box, 1920x1080",
-            "value": round(value, 3), "unit": "Mpaths/s", "spp_per_step": spp, "steps": steps,
-            "cpu_baseline": cpu, "gpu_over_cpu": round(value / cpu["value"], 1)}
+    return out
+
+
+def roofline_block(r, args, npix, spp, ms_per_step):
+    """Exclusive kernel times (HIP events, single stream) and exact work counts of PROFILE_PASSES more passes."""
+    n = min(PROFILE_PASSES, spp)
+    r.enable_profile(2)
+    r.read_profile_groups(reset=True)
+    r.render_passes(n, first_pass=0)
+    groups = r.read_profile_groups(reset=True)
+    r.enable_profile(0)
+    r.enable_stats(True)
+    r.read_stats(reset=True)
+    r.render_passes(n, first_pass=0)
+    stats = r.read_stats(reset=True)
+    r.enable_stats(False)
+    paths = npix * n
+    qb = queue_bytes(stats)
+    pmc = None
+    pmc_path = PMC_SUMMARY.get(args.workload)
+    if pmc_path and os.path.exists(os.path.join(ROOT, pmc_path)) and not (args.width or args.height) and \
+            (args.workload != "c4" or args.c4_subdivide == 2):
+        with open(os.path.join(ROOT, pmc_path)) as f:
+            pmc = json.load(f)["kernels"]
+
+    def pmc_sum(names, key):
+        return sum(pmc[k][key] for k in names if k in pmc and key in pmc[k]) if pmc else None
+
+    hbm = {}
+    for g, kernels in (("trace", ("k_trace", "k_tail")), ("shade", ("k_shade",)), ("resolve", ("k_resolve",))):
+        ms, launches = groups[g]["ms"], max(1, groups[g]["launches"])
+        e = {"kernels": list(kernels), "launches": launches, "avg_launch_us": round(ms * 1e3 / launches, 3),
+             "ms_per_64_passes": round(ms, 3),
+             "algorithmic_bytes_per_launch": round(qb[g] / launches),
+             "achieved_GBps": round(qb[g] / (ms * 1e-3) / 1e9, 1) if ms else None}
+        e["frac"] = round(e["achieved_GBps"] / HBM_PEAK_GBS, 4) if ms else None
+        per_path = pmc_sum(kernels, "hbm_bytes_per_path")
+        if per_path is not None:
+            e["traffic_bytes_per_launch"] = round(per_path * paths / launches)
+            e["traffic_GBps"] = round(per_path * paths / (ms * 1e-3) / 1e9, 1) if ms else None
+            e["traffic_frac"] = round(e["traffic_GBps"] / HBM_PEAK_GBS, 4) if ms else None
+        hbm[g] = e
+    total_bytes = sum(qb.values()) + npix * 24 * max(1, n // 32)
+    # every queue byte of a full step over the step's wall time must stay under the peak
+    step_bytes = total_bytes * spp / n
+    hbm["whole_step_vs_wall"] = {"algorithmic_bytes_per_step": round(step_bytes), "ms_per_step": ms_per_step,
+                                 "GBps": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                                 "frac": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    trace_s = groups["trace"]["ms"] * 1e-3
+    issue = None
+    valu_per_path = None
+    if pmc:
+        valu = pmc_sum(("k_trace", "k_tail"), "valu_insts")
+        valu_per_path = valu / json.load(open(os.path.join(ROOT, pmc_path)))["paths"]
+        lanes = sum(pmc[k]["valu_insts"] * pmc[k]["active_lanes_per_valu_inst"] for k in ("k_trace", "k_tail") if k in pmc) / valu
+        rate = valu_per_path * paths / trace_s
+        peak = SIMDS * PEAK_CLOCK_HZ / VALU_ISSUE_CYCLES
+        issue = {"valu_wave_insts_per_path": round(valu_per_path, 2), "achieved_Ginst_per_s": round(rate / 1e9, 2),
+                 "peak_Ginst_per_s": round(peak / 1e9, 1), "frac": round(rate / peak, 4),
+                 "active_lanes_per_valu_inst": round(lanes, 1), "lane_frac": round(lanes / 64, 3),
+                 "wave_time_waiting_on_memory_or_barrier": pmc["k_trace"].get("wave_time_waiting_on_memory_or_barrier"),
+                 "wave_time_issuing": pmc["k_trace"].get("wave_time_issuing"),
+                 "source": pmc_path + " (SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU of the same workload; kernel time measured in this run)"}
+    t = hbm["trace"]
+    out = {"kernel": "k_trace (+ k_tail): BVH traversal and intersection",
+           "share_of_device_time": round(groups["trace"]["ms"] / max(1e-9, sum(g["ms"] for g in groups.values())), 3)}
+    if issue:
+        out.update({"bound": "issue", "achieved": issue["achieved_Ginst_per_s"], "peak": issue["peak_Ginst_per_s"],
+                    "unit": "G wave64 vector instructions/s", "frac": issue["frac"]})
+    else:
+        out.update({"bound": "hbm", "achieved": t["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": t["frac"]})
+    out["traffic"] = t.get("traffic_bytes_per_launch")
+    out["note"] = ("k_trace is bound by vector-instruction issue and memory latency on cache-resident tables, not by HBM: its HBM "
+                   "side (hbm.trace) moves the queue records only; k_shade is the HBM-bound group (hbm.shade)")
+    out["issue"] = issue
+    out["hbm"] = hbm
+    out["tables"] = {"note": "BVH nodes and primitive records read per ray, served by LDS / L1 / L2, not HBM",
+                     "node_bytes_per_path": round(stats["nodes"] * NODE / paths, 1),
+                     "prim_bytes_per_path": round(stats["prims"] * PRIM / paths, 1),
+                     "texel_bytes_per_path": round(stats["texel_fetches"] * TEXEL / paths, 2)}
+    out["work"] = {"profiled_passes": n,
+                   "nodes_per_segment": round(stats["nodes"] / stats["segments"], 3),
+                   "prims_per_segment": round(stats["prims"] / stats["segments"], 3),
+                   "segments_per_path": round(stats["segments"] / stats["paths"], 3),
+                   "lane_utilisation_node_step": round(stats["nodes"] / max(1, 64 * stats["wave_node_steps"]), 3),
+                   "lane_utilisation_prim_test": round(stats["prims"] / max(1, 64 * stats["wave_leaf_steps"]), 3),
+                   "wave_node_steps_per_wave_ray": round(64 * stats["wave_node_steps"] / stats["segments"], 2),
+                   "wave_prim_tests_per_wave_ray": round(64 * stats["wave_leaf_steps"] / stats["segments"], 2),
+                   "queue_bytes_per_path": {g: round(b / paths, 1) for g, b in qb.items()}}
+    return out
 
 
 def main():
@@ -147,15 +276,24 @@ def main():
     npix = width * height
     accum = torch.zeros(height, width, 3, dtype=torch.float32, device=f"cuda:{local_rank}")
     r.bind_accumulator(accum.data_ptr())
+    # Everything that touches the accumulator (clears, the collective) is queued on the renderer's own stream, so it
+    # is ordered against the passes without blocking the host: the reduce of one step can still be in flight while
+    # the host queues the next step's launches behind it.
+    stream = torch.cuda.ExternalStream(r.stream_ptr(), device=torch.device("cuda", local_rank))
 
     def render(first, stride, n, rows=None):
         r.render_passes(n, first_pass=first, pass_stride=stride, rows=rows)
-        if world > 1:
-            r.synchronize()  # the renderer runs on its own stream; the collective runs on torch's
+        if world > 1 and rehearse:
+            r.synchronize()  # gloo stages through the host and knows nothing about streams
 
     def step():
         # rank r: passes r, r+N, ... of an (N * spp)-pass job, then one RCCL reduce of the accumulators
-        render_split(render, accum, spp * world, dst=0, split=args.split)
+        with torch.cuda.stream(stream):
+            render_split(render, accum, spp * world, dst=0, split=args.split)
+
+    def clear():
+        with torch.cuda.stream(stream):
+            accum.zero_()
 
     def fence():
         r.synchronize()
@@ -165,14 +303,10 @@ def main():
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        accum.zero_()
+        clear()
         step()
     fence()
-    profile = not args.no_profile
-    if profile:
-        r.enable_profile(True)
-        r.read_profile(reset=True)
-    accum.zero_()
+    clear()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -183,43 +317,11 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    trace_ms, trace_launches = r.read_profile(reset=True) if profile else (0.0, 0)
-    r.enable_profile(False)
+    ms_per_step = round(elapsed / args.steps * 1e3, 3)
 
     roofline = None
-    stats = None
-    if rank == 0 and profile and trace_launches:
-        # the same passes once more with the instrumented kernels (untimed): exact work counts of one step
-        r.enable_stats(True)
-        r.read_stats(reset=True)
-        r.render_passes(spp, first_pass=rank, pass_stride=world)
-        stats = r.read_stats(reset=True)
-        r.enable_stats(False)
-        bytes_per_step = trace_bytes(stats)
-        achieved = bytes_per_step * args.steps / (trace_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "k_trace", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                    "note": "algorithmic bytes are mostly BVH nodes and primitives served by L1/L2 (tables <= 15 MB), so "
-                            "achieved can exceed the HBM peak; traffic = HBM bytes per launch from rocprofv3 PMC",
-                    "avg_launch_us": round(trace_ms * 1e3 / trace_launches, 3), "launches": trace_launches,
-                    "kernel_ms_per_step": round(trace_ms / args.steps, 3),
-                    "algorithmic_bytes_per_path": round(bytes_per_step / (npix * spp), 2),
-                    "nodes_per_segment": round(stats["nodes"] / stats["segments"], 3),
-                    "prims_per_segment": round(stats["prims"] / stats["segments"], 3),
-                    "segments_per_path": round(stats["segments"] / stats["paths"], 3),
-                    "lane_utilisation_node_step": round(stats["nodes"] / max(1, 64 * stats["wave_node_steps"]), 3),
-                    "lane_utilisation_prim_test": round(stats["prims"] / max(1, 64 * stats["wave_leaf_steps"]), 3),
-                    "wave_node_steps_per_wave_ray": round(64 * stats["wave_node_steps"] / stats["segments"], 2),
-                    "wave_prim_tests_per_wave_ray": round(64 * stats["wave_leaf_steps"] / stats["segments"], 2)}
-        # HBM bytes of k_trace per launch: FETCH_SIZE / WRITE_SIZE cannot be read from inside this process, so
-        # the per-path figure of the committed rocprofv3 --pmc passes over this workload is scaled to this run.
-        pmc = os.path.join(ROOT, "profiles", f"r01_{args.workload}_pmc_traffic.json")
-        if os.path.exists(pmc) and not (args.width or args.height):
-            with open(pmc) as f:
-                per_path = json.load(f)["kernels"]["k_trace"]["hbm_bytes_per_path"]
-            roofline["traffic"] = round(per_path * npix * spp * args.steps / trace_launches)
-            roofline["algorithmic_bytes_per_launch"] = round(bytes_per_step * args.steps / trace_launches)
-            roofline["traffic_source"] = os.path.relpath(pmc, ROOT)
+    if rank == 0 and not args.no_profile:
+        roofline = roofline_block(r, args, npix, spp, ms_per_step)
     if world > 1:
         dist.barrier()
 
@@ -228,19 +330,14 @@ def main():
         out = {
             "metric": "Mpaths/s (pixels x spp / s)", "value": round(paths / elapsed / 1e6, 3), "unit": "Mpaths/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: " + {
-                "c1": "data/scene.json verbatim (Cornell walls, 4 968-triangle bunny, fog sphere, 4 985 shapes)",
-                "c2": "Book-1 random-spheres scene (484 spheres, Lambertian/metal/dielectric)",
-                "c3": "Cornell box, cosine + light-list mixture sampling",
-                "c4": ("bunny.obj subdivided to 79 488 triangles" if args.c4_subdivide == 2 else f"bunny.obj, {args.c4_subdivide} subdivision(s)")
-                      + " + earth-textured sphere in a Cornell box",
-                "c5": "zy_scene.json (noise/image-textured spheres in a Cornell box)"}[args.workload],
-                "width": width, "height": height, "spp_per_gpu_per_step": spp, "max_depth": scene.renderer_param.max_depth,
-                "paths_per_step": npix * spp * world,
-                "split": ("single GPU" if world == 1 else "sample-range (pass p on rank p mod N) + RCCL reduce" if args.split == "sample"
-                          else "tile (rank r renders its band of rows) + RCCL reduce")},
+            "config": {"workload": f"{args.workload}: " + (WORKLOADS[args.workload] if args.workload != "c4" or args.c4_subdivide == 2
+                                                          else f"bunny.obj, {args.c4_subdivide} subdivision(s) + earth-textured sphere in a Cornell box"),
+                       "width": width, "height": height, "spp_per_gpu_per_step": spp, "max_depth": scene.renderer_param.max_depth,
+                       "paths_per_step": npix * spp * world,
+                       "split": ("single GPU" if world == 1 else "sample-range (pass p on rank p mod N) + RCCL reduce" if args.split == "sample"
+                                 else "tile (rank r renders its band of rows) + RCCL reduce")},
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:
@@ -248,8 +345,8 @@ def main():
             out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
     r.close()
     if rank == 0:
-        if world == 1 and args.workload == "c2" and not args.no_bunny and not args.no_cpu_baseline and not (args.width or args.height):
-            out["bunny_scene"] = bunny_scene(Renderer, scenes, local_rank)
+        if world == 1 and args.workload == "c4" and not args.no_side and not (args.width or args.height):
+            out["spheres_scene"] = side_scene(Renderer, scenes, local_rank, with_cpu=not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -291,10 +291,20 @@ int v4r_trace_rays(v4r_renderer *r, uint32_t n, const float *host_origin, const 
 int v4r_stats_enable(v4r_renderer *r, int on);
 int v4r_stats_read(v4r_renderer *r, v4r_stats *out, int reset);
 
-/* Time every launch of the traversal kernel with a pair of HIP events recorded on the renderer's
- * stream, and read the accumulated device time and launch count (synchronises first). */
-int v4r_profile_enable(v4r_renderer *r, int on);
-int v4r_profile_read(v4r_renderer *r, double *trace_ms, uint64_t *trace_launches, int reset);
+/* Device time of the kernels from pairs of HIP events recorded on the stream they are launched on.
+ * mode 0: off.  mode 1: a pair around the traversal launches of every segment; batches keep running on all
+ * pipelines, so launches of different streams share the GPU and a pair's duration is an upper bound.
+ * mode 2: every batch runs on pipeline 0 -- kernels run one after the other, durations are exclusive --
+ * with pairs around the traversal launches, the shading launches and the resolve launch of every segment
+ * (slower than mode 0: nothing overlaps).  v4r_profile_read returns the traversal group: summed milliseconds
+ * and number of event pairs; v4r_profile_read_groups returns, per group, milliseconds, kernel launches and
+ * event pairs.  Both synchronise first. */
+#define V4R_PROFILE_TRACE 0   /* k_trace (first and second launch of a segment) and k_tail */
+#define V4R_PROFILE_SHADE 1   /* k_shade, all material classes of a segment             */
+#define V4R_PROFILE_RESOLVE 2 /* k_resolve                                               */
+int v4r_profile_enable(v4r_renderer *r, int mode);
+int v4r_profile_read(v4r_renderer *r, double *trace_ms, uint64_t *trace_pairs, int reset);
+int v4r_profile_read_groups(v4r_renderer *r, double ms[3], uint64_t launches[3], uint64_t pairs[3], int reset);
 
 /* Block until every queued pass has finished. */
 int v4r_synchronize(v4r_renderer *r);

@@ -143,6 +143,7 @@ struct WideTree;
 struct Ctx {
     const v4r_scene_desc *s;
     uint32_t seg_key = 0;  // key of the segment being traced / shaded
+    uint32_t packet_light = 0xFFFFFFFFu;  // packet mode: the light index HittableGroup::generate drew for the whole packet
     Counters cnt;
     const WideTree *wide = nullptr;  // mode 1 only
 };
@@ -347,6 +348,7 @@ inline bool slab(const float *lo, const float *hi, const Ray &r, float t_min, fl
 struct Closest {
     uint32_t prim = 0xFFFFFFFFu;
     Hit hit;
+    uint32_t first = 0xFFFFFFFFu;  // lowest-index candidate shape the ray hits at all (orders renderer.rs:176's hit_ray_indices)
 };
 
 // closest-hit rule of ray_color, renderer.rs:149-183: strictly smaller t wins; shapes are visited in
@@ -355,6 +357,7 @@ inline void consider(Ctx &ctx, Closest &c, uint32_t prim_index, const Ray &r) {
     ctx.cnt.prims++;
     Hit h = hit_prim(ctx, ctx.s->prims[prim_index], prim_index, r, EPSILON, INF);
     if (!h.mask) return;
+    if (prim_index < c.first) c.first = prim_index;
     if (c.hit.t > h.t || (c.hit.t == h.t && c.hit.mask && prim_index < c.prim)) {
         c.prim = prim_index;
         c.hit = h;
@@ -764,6 +767,51 @@ V3 light_generate(Ctx &ctx, uint32_t prim_index, V3 origin, float u0, float u1) 
     return light_generate_object(pr, origin, u0, u1);
 }
 
+// The two ingredients of Samplable::value for one lane of a SIMD packet (aa_rect.rs:151-180, triangle.rs:103-132,
+// sphere.rs:100-131, through TransformHittable::value): does this lane's direction hit the light, and the density
+// the lane is given when the hit record of its packet is not all-miss.  For rectangles and triangles that density is
+// computed from the un-clipped plane hit (t may be negative); a sphere masks with its own hit.
+float light_probe(Ctx &ctx, uint32_t prim_index, V3 origin, V3 dir, bool &hit, bool &per_lane) {
+    const v4r_prim &pr = ctx.s->prims[prim_index];
+    if (pr.xform != V4R_NO_XFORM) {
+        const v4r_xform &x = ctx.s->xforms[pr.xform];
+        origin = mat_mul(x.inv, origin) + v3(x.inv_t);
+        dir = normalize(mat_mul(x.inv, dir));
+    }
+    Ray r{origin, dir};
+    per_lane = false;
+    hit = false;
+    switch (pr.type & V4R_PRIM_TYPE_MASK) {
+        case V4R_PRIM_SPHERE: {
+            per_lane = true;
+            Hit h = hit_sphere(pr.f, r, EPSILON, INF);
+            hit = h.mask;
+            if (!h.mask) return 0.0f;
+            float radius = pr.f[3];
+            float cos_theta_max = std::sqrt(1.0f - radius * radius / norm2(v3(pr.f) - origin));
+            float solid_angle = TWO_PI * (1.0f - cos_theta_max);
+            return solid_angle > 0.0f ? 1.0f / solid_angle : INF;
+        }
+        case V4R_PRIM_XY_RECT:
+        case V4R_PRIM_YZ_RECT:
+        case V4R_PRIM_ZX_RECT: {
+            Hit h = hit_rect(pr, r, EPSILON, INF, true);
+            hit = h.mask;
+            float area = (pr.f[1] - pr.f[0]) * (pr.f[3] - pr.f[2]);
+            float cosine = std::fabs(dot(dir, h.normal));
+            return cosine > 0.0f ? (h.t * h.t) / (cosine * area) : INF;
+        }
+        case V4R_PRIM_TRIANGLE: {
+            Hit h = hit_triangle(pr, ctx.s->tri_shading[pr.aux], r, EPSILON, INF, true);
+            hit = h.mask;
+            float area = norm(cross(v3(pr.f + 3), v3(pr.f + 6))) * 0.5f;
+            float cosine = std::fabs(dot(dir, h.normal));
+            return cosine > 0.0f ? (h.t * h.t) / (cosine * area) : INF;
+        }
+        default: per_lane = true; return 0.0f;
+    }
+}
+
 // HittableGroup::value over the light list, hittables/group.rs:76-89
 float lights_value(Ctx &ctx, V3 origin, V3 dir) {
     uint32_t n = ctx.s->n_lights;
@@ -794,6 +842,7 @@ struct Scatter {
     V3 coef{0, 0, 0};
     V3 dir{0, 0, 0};
     V3 emitted{0, 0, 0};
+    float pdf_v = 0.0f;  // packet mode only: the material pdf's value for `dir`, `coef` still being the bare attenuation
 };
 
 // Material::emitted + Material::scatter + the pdf branch of ray_color (renderer.rs:218-263)
@@ -815,16 +864,21 @@ Scatter shade(Ctx &ctx, uint32_t prim_index, const Ray &ray, const Hit &h) {
             if (s->n_lights != 0) {  // renderer.rs:234-244
                 // MixturePdf::generate, pdf/mixture.rs:27-32: both members generate, then select
                 bool pick_light = draw(key, DIM_SCATTER + 0) < 0.5f;
-                // HittableGroup::generate, hittables/group.rs:91-95
+                // HittableGroup::generate, hittables/group.rs:91-95 (one index per SIMD packet there: `packet_light`)
                 uint32_t n = s->n_lights;
-                uint32_t li = (uint32_t)(((uint64_t)draw_u32(key, DIM_SCATTER + 1) * n) >> 32);
+                uint32_t li = ctx.packet_light != 0xFFFFFFFFu ? ctx.packet_light : (uint32_t)(((uint64_t)draw_u32(key, DIM_SCATTER + 1) * n) >> 32);
                 V3 d_light = light_generate(ctx, s->lights[li], h.p, draw(key, DIM_SCATTER + 2), draw(key, DIM_SCATTER + 3));
                 V3 d_cos = cosine_generate(h.normal, draw(key, DIM_SCATTER + 4), draw(key, DIM_SCATTER + 5));
                 V3 dir = pick_light ? d_light : d_cos;
                 float pdf_v = cosine_value(h.normal, dir);
+                out.dir = dir;
+                if (ctx.packet_light != 0xFFFFFFFFu) {  // the packet finishes the coefficient: see shade_packet
+                    out.coef = attenuation;
+                    out.pdf_v = pdf_v;
+                    return out;
+                }
                 float mix_v = 0.5f * lights_value(ctx, h.p, dir) + 0.5f * pdf_v;  // pdf/mixture.rs:22-25
                 out.coef = attenuation * pdf_v / mix_v;
-                out.dir = dir;
             } else {  // renderer.rs:245-255
                 out.dir = cosine_generate(h.normal, draw(key, DIM_SCATTER + 4), draw(key, DIM_SCATTER + 5));
                 out.coef = attenuation;
@@ -913,6 +967,159 @@ V3 path_radiance(Ctx &ctx, uint64_t seed, uint32_t pass, uint32_t pixel, int mod
         ray = Ray{c.hit.p, sc.dir};
     }
     return thr * v3(s->environment);  // renderer.rs:128-130
+}
+
+// ---- packet-faithful pass (mode 2) ----------------------------------------------------------------
+// ray_color as the reference runs it (renderer.rs:123-320): breadth first over the whole image, one recursion
+// level at a time, with the reference's grouping of rays into 8-lane packets wherever the grouping changes a
+// result.  Two things do: HittableGroup::generate draws ONE light index per packet (group.rs:91-95), and
+// Samplable::value of a rectangle or triangle light returns 0 for every lane when no lane of the packet hits the
+// light, the un-clipped plane density for every lane otherwise (aa_rect.rs:158-179, triangle.rs:110-131).
+// The packets of the shading step are: the rays whose closest hit is shape s, for ascending s (BTreeMap,
+// renderer.rs:189-204), in the order the rays first received a hit -- ascending (lowest-index candidate shape
+// the ray hits, ray index), renderer.rs:152-183 -- cut into groups of LANES = 8 (renderer.rs:214-217); the
+// rays of the next level are the scattered rays in that same order (renderer.rs:264-271).
+// Per-ray arithmetic and random streams are those of path_radiance (mode 0): throughput carried as a product.
+constexpr uint32_t LANES = 8;  // f32x8, src/main.rs:14
+
+struct LevelRay {
+    Ray ray;
+    V3 thr;
+    uint32_t pixel;
+    PathKey pk;
+};
+
+// The scatter step of one packet of `n` <= LANES rays that hit shape `prim_index` (renderer.rs:214-272).
+void shade_packet(Ctx &ctx, uint32_t prim_index, uint32_t seg, const LevelRay *const *rays, const Hit *hits, uint32_t n, Scatter *out) {
+    const v4r_scene_desc *s = ctx.s;
+    const v4r_material &m = s->materials[s->prim_material[prim_index]];
+    const bool mixture = m.kind == V4R_MAT_LAMBERTIAN && s->n_lights != 0;
+    if (mixture)  // one index for the packet; lane 0's stream stands in for the packet's draw
+        ctx.packet_light = (uint32_t)(((uint64_t)draw_u32(segment_key(rays[0]->pk, seg), DIM_SCATTER + 1) * s->n_lights) >> 32);
+    for (uint32_t k = 0; k < n; ++k) {
+        ctx.seg_key = segment_key(rays[k]->pk, seg);
+        out[k] = shade(ctx, prim_index, rays[k]->ray, hits[k]);
+    }
+    ctx.packet_light = 0xFFFFFFFFu;
+    if (!mixture) return;
+    // MixturePdf::value over the packet (mixture.rs:22-25) with HittableGroup::value (group.rs:76-89)
+    float light_sum[LANES] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const float weight = 1.0f / (float)s->n_lights;
+    for (uint32_t l = 0; l < s->n_lights; ++l) {
+        float density[LANES];
+        bool any = false, per_lane = false;
+        for (uint32_t k = 0; k < n; ++k) {
+            bool hit;
+            density[k] = light_probe(ctx, s->lights[l], hits[k].p, out[k].dir, hit, per_lane);
+            any = any || hit;
+        }
+        for (uint32_t k = 0; k < n; ++k) light_sum[k] += weight * ((per_lane || any) ? density[k] : 0.0f);
+    }
+    for (uint32_t k = 0; k < n; ++k) {
+        float mix_v = 0.5f * light_sum[k] + 0.5f * out[k].pdf_v;
+        out[k].coef = out[k].coef * out[k].pdf_v / mix_v;
+    }
+}
+
+template <class F>
+void parallel_for(uint32_t n, int n_threads, F body) {  // body(begin, end, thread)
+    std::atomic<uint32_t> next{0};
+    const uint32_t chunk = 1024;
+    auto worker = [&](int tid) {
+        while (true) {
+            uint32_t begin = next.fetch_add(chunk);
+            if (begin >= n) break;
+            body(begin, std::min(n, begin + chunk), tid);
+        }
+    };
+    std::vector<std::thread> threads;
+    for (int t = 1; t < n_threads; ++t) threads.emplace_back(worker, t);
+    worker(0);
+    for (auto &t : threads) t.join();
+}
+
+void render_pass_packets(const v4r_scene_desc *s, uint64_t seed, uint32_t pass, float *accum, int n_threads, std::vector<Counters> &counters) {
+    const uint32_t npix = s->width * s->height;
+    std::vector<LevelRay> cur(npix), next;
+    parallel_for(npix, n_threads, [&](uint32_t b, uint32_t e, int) {
+        for (uint32_t pix = b; pix < e; ++pix) {
+            PathKey pk = path_key(seed, pass, pix);
+            cur[pix] = LevelRay{camera_ray(s, pix / s->width, pix % s->width, segment_key(pk, 0), false), v3(1, 1, 1), pix, pk};
+        }
+    });
+    auto add = [&](uint32_t pixel, V3 c) {
+        accum[3 * (size_t)pixel] += c.x;
+        accum[3 * (size_t)pixel + 1] += c.y;
+        accum[3 * (size_t)pixel + 2] += c.z;
+    };
+    for (auto &c : counters) c.paths += 0;
+    counters[0].paths += npix;
+    std::vector<Closest> found;
+    struct Order {
+        uint32_t shape, first, ray;
+    };
+    std::vector<Order> order;
+    std::vector<uint32_t> packet_start;
+    std::vector<Scatter> scattered;
+    for (uint32_t seg = 0; seg < s->max_depth && !cur.empty(); ++seg) {
+        const uint32_t n = (uint32_t)cur.size();
+        found.assign(n, Closest{});
+        parallel_for(n, n_threads, [&](uint32_t b, uint32_t e, int tid) {
+            Ctx ctx{s};
+            for (uint32_t i = b; i < e; ++i) {
+                ctx.seg_key = segment_key(cur[i].pk, seg);
+                found[i] = trace(ctx, cur[i].ray, 0);
+            }
+            counters[(size_t)tid].add(ctx.cnt);
+        });
+        order.clear();
+        for (uint32_t i = 0; i < n; ++i) {
+            if (!found[i].hit.mask) add(cur[i].pixel, cur[i].thr * v3(s->background));  // renderer.rs:184
+            else order.push_back({found[i].prim, found[i].first, i});
+        }
+        std::sort(order.begin(), order.end(), [](const Order &a, const Order &b) {
+            if (a.shape != b.shape) return a.shape < b.shape;
+            if (a.first != b.first) return a.first < b.first;
+            return a.ray < b.ray;
+        });
+        packet_start.clear();
+        for (size_t k = 0; k < order.size();) {
+            size_t end = k;
+            while (end < order.size() && order[end].shape == order[k].shape) ++end;
+            for (size_t q = k; q < end; q += LANES) packet_start.push_back((uint32_t)q);
+            k = end;
+        }
+        scattered.assign(order.size(), Scatter{});
+        parallel_for((uint32_t)packet_start.size(), n_threads, [&](uint32_t b, uint32_t e, int tid) {
+            Ctx ctx{s};
+            for (uint32_t p = b; p < e; ++p) {
+                const uint32_t q = packet_start[p];
+                uint32_t lanes = 0;
+                const LevelRay *rays[LANES];
+                Hit hits[LANES];
+                while (lanes < LANES && q + lanes < order.size() && order[q + lanes].shape == order[q].shape) {
+                    rays[lanes] = &cur[order[q + lanes].ray];
+                    hits[lanes] = found[order[q + lanes].ray].hit;
+                    ++lanes;
+                }
+                shade_packet(ctx, order[q].shape, seg, rays, hits, lanes, &scattered[q]);
+            }
+            counters[(size_t)tid].add(ctx.cnt);
+        });
+        next.clear();
+        for (size_t k = 0; k < order.size(); ++k) {
+            const LevelRay &r = cur[order[k].ray];
+            const Scatter &sc = scattered[k];
+            if (!sc.scattered) {  // renderer.rs:218-230,261
+                add(r.pixel, r.thr * sc.emitted);
+                continue;
+            }
+            V3 thr = r.thr * sc.coef;  // renderer.rs:299-318
+            if (seg + 1 >= s->max_depth) add(r.pixel, thr * v3(s->environment));  // renderer.rs:128-130
+            else next.push_back(LevelRay{Ray{found[order[k].ray].hit.p, sc.dir}, thr, r.pixel, r.pk});
+        }
+        cur.swap(next);
+    }
 }
 
 int validate(const v4r_scene_desc *s) {

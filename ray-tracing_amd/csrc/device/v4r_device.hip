@@ -770,12 +770,19 @@ struct v4r_renderer {
     uint32_t tail_segment = 0;  // first segment that k_tail finishes in one launch; 0 = none
     bool any_noise = false;
     bool counting = false;
-    // HIP-event timing of the k_trace launches (v4r_profile_*)
-    bool profiling = false;
-    std::vector<hipEvent_t> ev_pool;  // pairs: start, stop
+    // HIP-event timing of the kernel launches (v4r_profile_*): 0 = off; 1 = a pair of events around the traversal
+    // launches of every segment; 2 = every batch on pipeline 0 (so the kernels run one after the other and a
+    // duration is exclusive) with pairs around the traversal, the shading and the resolve launches
+    int profiling = 0;
+    struct EventPair {
+        hipEvent_t start, stop;
+        int group;           // V4R_PROFILE_TRACE / _SHADE / _RESOLVE
+        uint32_t launches;   // kernel launches between the two events
+    };
+    std::vector<EventPair> ev_pool;
     size_t ev_used = 0;
-    double trace_ms = 0.0;
-    uint64_t trace_launches = 0;
+    double group_ms[3] = {0.0, 0.0, 0.0};
+    uint64_t group_launches[3] = {0, 0, 0}, group_pairs[3] = {0, 0, 0};
     bool has_class[CLS_COUNT] = {false, false, false, false, false, false};
     int media_mode = MEDIA_NONE;  // selects the kernel instantiations (see traverse)
     bool class_noise[CLS_COUNT] = {false, false, false, false, false, false};  // a material of the class uses a noise texture
@@ -1423,35 +1430,36 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
 
 // Instantiations of k_trace: work counters x media mode x (segment 0 generates its camera rays) x (second launch).
 template <bool COUNT, int MEDIA, bool PRIMARY>
-void launch_trace_as(v4r_renderer *r, Pipe &pipe, uint32_t seg, const PrimaryArgs &A) {
+uint32_t launch_trace_as(v4r_renderer *r, Pipe &pipe, uint32_t seg, const PrimaryArgs &A) {
     dim3 grid(r->grid_trace), block(BLOCK);
     constexpr int R = TRACE_RAYS_PER_THREAD;
     // the first segments hold nearly all rays: there a wave gives its last few rays up to a second launch
     uint32_t give_up = seg < r->give_up_segments ? r->give_up_lanes : 0u;
     hipLaunchKernelGGL((k_trace<COUNT, R, MEDIA, PRIMARY, false>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A, give_up);
     if (give_up) hipLaunchKernelGGL((k_trace<COUNT, R, MEDIA, PRIMARY, true>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A, 0u);
+    return give_up ? 2u : 1u;
 }
 template <bool COUNT, int MEDIA>
-void launch_trace_media(v4r_renderer *r, Pipe &pipe, uint32_t seg, const PrimaryArgs &A) {
-    if (seg == 0) launch_trace_as<COUNT, MEDIA, true>(r, pipe, seg, A);
-    else launch_trace_as<COUNT, MEDIA, false>(r, pipe, seg, A);
+uint32_t launch_trace_media(v4r_renderer *r, Pipe &pipe, uint32_t seg, const PrimaryArgs &A) {
+    if (seg == 0) return launch_trace_as<COUNT, MEDIA, true>(r, pipe, seg, A);
+    return launch_trace_as<COUNT, MEDIA, false>(r, pipe, seg, A);
 }
 template <bool COUNT>
-void launch_trace_counting(v4r_renderer *r, Pipe &pipe, uint32_t seg, const PrimaryArgs &A) {
+uint32_t launch_trace_counting(v4r_renderer *r, Pipe &pipe, uint32_t seg, const PrimaryArgs &A) {
     switch (r->media_mode) {
-        case MEDIA_IN_TREE: launch_trace_media<COUNT, MEDIA_IN_TREE>(r, pipe, seg, A); break;
-        case MEDIA_DIRECT: launch_trace_media<COUNT, MEDIA_DIRECT>(r, pipe, seg, A); break;
-        default: launch_trace_media<COUNT, MEDIA_NONE>(r, pipe, seg, A); break;
+        case MEDIA_IN_TREE: return launch_trace_media<COUNT, MEDIA_IN_TREE>(r, pipe, seg, A);
+        case MEDIA_DIRECT: return launch_trace_media<COUNT, MEDIA_DIRECT>(r, pipe, seg, A);
+        default: return launch_trace_media<COUNT, MEDIA_NONE>(r, pipe, seg, A);
     }
 }
-void launch_trace(v4r_renderer *r, Pipe &pipe, uint32_t seg, const PrimaryArgs &A) {
-    if (r->counting) launch_trace_counting<true>(r, pipe, seg, A);
-    else launch_trace_counting<false>(r, pipe, seg, A);
+// Returns the number of kernels launched.
+uint32_t launch_trace(v4r_renderer *r, Pipe &pipe, uint32_t seg, const PrimaryArgs &A) {
+    return r->counting ? launch_trace_counting<true>(r, pipe, seg, A) : launch_trace_counting<false>(r, pipe, seg, A);
 }
 
 template <int CLS>
-void launch_shade(v4r_renderer *r, Pipe &pipe, uint32_t seg) {
-    if (!r->has_class[CLS]) return;
+uint32_t launch_shade(v4r_renderer *r, Pipe &pipe, uint32_t seg) {
+    if (!r->has_class[CLS]) return 0u;
     dim3 grid(r->grid_shade), block(BLOCK);
     // Lambertian materials are classed by noise already; metal and dielectric have no texture
     constexpr bool maybe_noise = CLS == CLS_LIGHT || CLS == CLS_ISOTROPIC;
@@ -1462,6 +1470,7 @@ void launch_shade(v4r_renderer *r, Pipe &pipe, uint32_t seg) {
         if (r->counting) hipLaunchKernelGGL((k_shade<CLS, true, false>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg);
         else hipLaunchKernelGGL((k_shade<CLS, false, false>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg);
     }
+    return 1u;
 }
 
 template <bool COUNT, int MEDIA>
@@ -1504,38 +1513,55 @@ int run_batch(v4r_renderer *r, Pipe &pipe, uint64_t seed, uint32_t first_pass, u
     PrimaryArgs primary{(uint32_t)seed, (uint32_t)(seed >> 32), first_pass, pass_stride, n_paths, band_pix, band_offset, order};
     // segments 0 .. n_wavefront-1 run as one trace launch (or two) and one shading launch per class; one k_tail finishes the rest
     const uint32_t n_wavefront = r->tail_segment >= 1u && r->tail_segment < r->S.max_depth ? r->tail_segment : r->S.max_depth;
+    // v4r_profile_*: a pair of HIP events on this pipeline's stream around a group of launches
+    auto bracket_begin = [&](int group, v4r_renderer::EventPair *&pair) -> int {
+        pair = nullptr;
+        if (!r->profiling || (r->profiling == 1 && group != V4R_PROFILE_TRACE)) return V4R_OK;
+        if (r->ev_used == r->ev_pool.size()) {
+            v4r_renderer::EventPair e{};
+            HIP_TRY(hipEventCreate(&e.start));
+            HIP_TRY(hipEventCreate(&e.stop));
+            r->ev_pool.push_back(e);
+        }
+        pair = &r->ev_pool[r->ev_used++];
+        pair->group = group;
+        pair->launches = 0;
+        HIP_TRY(hipEventRecord(pair->start, pipe.stream));
+        return V4R_OK;
+    };
+    auto bracket_end = [&](v4r_renderer::EventPair *pair, uint32_t launches) -> int {
+        if (!pair) return V4R_OK;
+        pair->launches = launches;
+        HIP_TRY(hipEventRecord(pair->stop, pipe.stream));
+        return V4R_OK;
+    };
     for (uint32_t seg = 0; seg <= n_wavefront && seg < r->S.max_depth; ++seg) {
         const bool tail = seg == n_wavefront;
-        hipEvent_t ev0 = nullptr, ev1 = nullptr;
-        if (r->profiling) {
-            if (r->ev_used + 2 > r->ev_pool.size()) {
-                hipEvent_t a, b;
-                HIP_TRY(hipEventCreate(&a));
-                HIP_TRY(hipEventCreate(&b));
-                r->ev_pool.push_back(a);
-                r->ev_pool.push_back(b);
-            }
-            ev0 = r->ev_pool[r->ev_used++];
-            ev1 = r->ev_pool[r->ev_used++];
-            HIP_TRY(hipEventRecord(ev0, pipe.stream));
-        }
+        v4r_renderer::EventPair *pair = nullptr;
+        if (int rc = bracket_begin(V4R_PROFILE_TRACE, pair)) return rc;
+        uint32_t launches = 1;
         if (tail) launch_tail(r, pipe, seg);  // timed with the trace launches: nearly all of it is traversal
-        else launch_trace(r, pipe, seg, primary);
-        if (r->profiling) HIP_TRY(hipEventRecord(ev1, pipe.stream));
+        else launches = launch_trace(r, pipe, seg, primary);
+        if (int rc = bracket_end(pair, launches)) return rc;
         if (tail) break;
-        launch_shade<CLS_LIGHT>(r, pipe, seg);
-        launch_shade<CLS_LAMBERT>(r, pipe, seg);
-        launch_shade<CLS_LAMBERT_NOISE>(r, pipe, seg);
-        launch_shade<CLS_METAL>(r, pipe, seg);
-        launch_shade<CLS_DIELECTRIC>(r, pipe, seg);
-        launch_shade<CLS_ISOTROPIC>(r, pipe, seg);
+        if (int rc = bracket_begin(V4R_PROFILE_SHADE, pair)) return rc;
+        launches = launch_shade<CLS_LIGHT>(r, pipe, seg);
+        launches += launch_shade<CLS_LAMBERT>(r, pipe, seg);
+        launches += launch_shade<CLS_LAMBERT_NOISE>(r, pipe, seg);
+        launches += launch_shade<CLS_METAL>(r, pipe, seg);
+        launches += launch_shade<CLS_DIELECTRIC>(r, pipe, seg);
+        launches += launch_shade<CLS_ISOTROPIC>(r, pipe, seg);
+        if (int rc = bracket_end(pair, launches)) return rc;
     }
     if (r->S.max_depth == 0)
         hipLaunchKernelGGL(k_fill_rad, dim3(r->grid_stream), dim3(BLOCK), 0, pipe.stream, pipe.Q, n_paths, r->S.env[0], r->S.env[1], r->S.env[2]);
     // accumulate in batch order: this batch's k_resolve runs after the previous batch's
     if (r->last_resolve && r->last_resolve != pipe.done) HIP_TRY(hipStreamWaitEvent(pipe.stream, r->last_resolve, 0));
+    v4r_renderer::EventPair *resolve_pair = nullptr;
+    if (int rc = bracket_begin(V4R_PROFILE_RESOLVE, resolve_pair)) return rc;
     hipLaunchKernelGGL(k_resolve, dim3(r->grid_stream), dim3(BLOCK), 0, pipe.stream, pipe.Q, r->accum + 3 * (size_t)band_offset, band_pix,
                        n_batch_passes);
+    if (int rc = bracket_end(resolve_pair, 1u)) return rc;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(pipe.done, pipe.stream));
     r->last_resolve = pipe.done;
@@ -1601,7 +1627,10 @@ void v4r_renderer_destroy(v4r_renderer *r) {
     for (auto &p : r->pipes)
         for (void *q : p.allocations) (void)hipFree(q);
     for (void *p : r->allocations) (void)hipFree(p);
-    for (hipEvent_t e : r->ev_pool) (void)hipEventDestroy(e);
+    for (auto &e : r->ev_pool) {
+        (void)hipEventDestroy(e.start);
+        (void)hipEventDestroy(e.stop);
+    }
     delete r;
 }
 
@@ -1621,7 +1650,9 @@ int v4r_render_rows(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_
     // A job of fewer batches than pipelines is cut into one piece per pipeline (multiples of 16 passes, the
     // camera-ray tile) so that the pieces overlap: measured +12 % for a 32-pass 1080p job and +6 % for 128 passes
     // of 800x800; jobs of many batches are better off with few large ones.
-    const uint32_t n_pipes = (uint32_t)r->pipes.size();
+    // profile mode 2 keeps every batch on pipeline 0, so that kernels do not overlap and the event pairs time them alone
+    const uint32_t n_pipes = r->profiling == 2 ? 1u : (uint32_t)r->pipes.size();
+    if (r->profiling == 2) r->next_pipe = 0;
     if ((n_passes + batch - 1u) / batch < n_pipes) {
         uint32_t share = (n_passes + n_pipes - 1u) / n_pipes;
         if (share >= 16u) share = (share + 15u) & ~15u;
@@ -1631,7 +1662,7 @@ int v4r_render_rows(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_
     while (done < n_passes) {
         uint32_t nb = std::min(batch, n_passes - done);
         Pipe &pipe = r->pipes[r->next_pipe];
-        r->next_pipe = (r->next_pipe + 1) % (uint32_t)r->pipes.size();
+        r->next_pipe = (r->next_pipe + 1) % n_pipes;
         if (int rc = ensure_pipe(r, pipe, (size_t)nb * band_pix)) return rc;
         if (int rc = run_batch(r, pipe, seed, first_pass + done * pass_stride, pass_stride, nb, row0, n_rows)) return rc;
         done += nb;
@@ -1808,39 +1839,54 @@ int v4r_stats_read(v4r_renderer *r, v4r_stats *out, int reset) {
     return V4R_OK;
 }
 
-// Fold the recorded event pairs into the running totals (the stream must be idle).
+// Fold the recorded event pairs into the running totals (every pipeline must be idle).
 static int profile_collect(v4r_renderer *r) {
-    for (size_t i = 0; i + 1 < r->ev_used; i += 2) {
+    for (size_t i = 0; i < r->ev_used; ++i) {
+        const auto &e = r->ev_pool[i];
         float ms = 0.0f;
-        HIP_TRY(hipEventElapsedTime(&ms, r->ev_pool[i], r->ev_pool[i + 1]));
-        r->trace_ms += ms;
-        r->trace_launches++;
+        HIP_TRY(hipEventElapsedTime(&ms, e.start, e.stop));
+        r->group_ms[e.group] += ms;
+        r->group_launches[e.group] += e.launches;
+        r->group_pairs[e.group]++;
     }
     r->ev_used = 0;
     return V4R_OK;
 }
 
-int v4r_profile_enable(v4r_renderer *r, int on) {
+int v4r_profile_enable(v4r_renderer *r, int mode) {
     if (!r) return set_error(V4R_E_INVALID, "NULL renderer");
+    if (mode < 0 || mode > 2) return set_error(V4R_E_INVALID, "profile mode must be 0, 1 or 2");
     std::lock_guard<std::recursive_mutex> hold(r->mu);
     HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(hipStreamSynchronize(r->stream));
     if (int rc = profile_collect(r)) return rc;
-    r->profiling = on != 0;
+    r->profiling = mode;
     return V4R_OK;
 }
 
 int v4r_profile_read(v4r_renderer *r, double *trace_ms, uint64_t *trace_launches, int reset) {
+    double ms[3];
+    uint64_t launches[3], pairs[3];
+    if (int rc = v4r_profile_read_groups(r, ms, launches, pairs, reset)) return rc;
+    if (trace_ms) *trace_ms = ms[V4R_PROFILE_TRACE];
+    if (trace_launches) *trace_launches = pairs[V4R_PROFILE_TRACE];
+    return V4R_OK;
+}
+
+int v4r_profile_read_groups(v4r_renderer *r, double ms[3], uint64_t launches[3], uint64_t pairs[3], int reset) {
     if (!r) return set_error(V4R_E_INVALID, "NULL renderer");
     std::lock_guard<std::recursive_mutex> hold(r->mu);
     HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(hipStreamSynchronize(r->stream));
     if (int rc = profile_collect(r)) return rc;
-    if (trace_ms) *trace_ms = r->trace_ms;
-    if (trace_launches) *trace_launches = r->trace_launches;
-    if (reset) {
-        r->trace_ms = 0.0;
-        r->trace_launches = 0;
+    for (int g = 0; g < 3; ++g) {
+        if (ms) ms[g] = r->group_ms[g];
+        if (launches) launches[g] = r->group_launches[g];
+        if (pairs) pairs[g] = r->group_pairs[g];
+        if (reset) {
+            r->group_ms[g] = 0.0;
+            r->group_launches[g] = r->group_pairs[g] = 0;
+        }
     }
     return V4R_OK;
 }

@@ -617,8 +617,17 @@ class Renderer:
                                               prim.ctypes.data_as(C.POINTER(C.c_uint32)), t.ctypes.data_as(fp)))
         return prim, t
 
-    def enable_profile(self, on: bool = True) -> None:
-        check_dev(device_lib().v4r_profile_enable(self._h, int(on)))
+    def enable_profile(self, mode=True) -> None:
+        """0 / False: off; 1 / True: event pairs around the traversal launches; 2: exclusive per-kernel-group timing
+        (every batch on one stream, pairs around traversal, shading and resolve launches)."""
+        check_dev(device_lib().v4r_profile_enable(self._h, int(mode)))
+
+    def read_profile_groups(self, reset: bool = False) -> dict:
+        """Per kernel group ("trace", "shade", "resolve"): device milliseconds, kernel launches, event pairs."""
+        ms, launches, pairs = (C.c_double * 3)(), (C.c_uint64 * 3)(), (C.c_uint64 * 3)()
+        check_dev(device_lib().v4r_profile_read_groups(self._h, ms, launches, pairs, int(reset)))
+        return {name: {"ms": float(ms[g]), "launches": int(launches[g]), "pairs": int(pairs[g])}
+                for g, name in enumerate(("trace", "shade", "resolve"))}
 
     def read_profile(self, reset: bool = False):
         """(device milliseconds spent in the traversal kernel, number of its launches), from HIP events."""

@@ -183,7 +183,7 @@ DEVICE_SYMBOLS = [
     "v4r_abi_version", "v4r_last_error", "v4r_renderer_create", "v4r_renderer_destroy", "v4r_render", "v4r_render_rows",
     "v4r_accum_bind", "v4r_reduce", "v4r_accum_clear", "v4r_accum_read", "v4r_accum_write", "v4r_accum_device", "v4r_tonemap_u8",
     "v4r_trace_primary", "v4r_trace_rays", "v4r_stats_enable", "v4r_stats_read", "v4r_synchronize",
-    "v4r_stream", "v4r_pass_count", "v4r_profile_enable", "v4r_profile_read",
+    "v4r_stream", "v4r_pass_count", "v4r_profile_enable", "v4r_profile_read", "v4r_profile_read_groups",
 ]
 
 
@@ -223,6 +223,7 @@ def device_lib():
     _sig(lib.v4r_pass_count, i32, vp, up)
     _sig(lib.v4r_profile_enable, i32, vp, i32)
     _sig(lib.v4r_profile_read, i32, vp, C.POINTER(C.c_double), C.POINTER(u64), i32)
+    _sig(lib.v4r_profile_read_groups, i32, vp, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64), i32)
     _dev = lib
     return lib
 

@@ -5,8 +5,8 @@ OUT=gpurun_out/bench_all
 mkdir -p $OUT
 run() { name=$1; shift; timeout -k 10 500 python bench.py "$@" > $OUT/$name.json 2> $OUT/$name.err || exit 1; echo $name $(python -c "import json,sys; d=json.loads(open('$OUT/$name.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['cpu_baseline']['value'], d.get('gpu_over_cpu'))"); }
 run c2 --workload c2 &&
-run c1 --workload c1 --spp 128 --no-bunny &&
-run c3 --workload c3 --spp 128 --no-bunny &&
-run c4 --workload c4 --spp 256 --no-bunny &&
-run c5 --workload c5 --spp 128 --no-bunny &&
-run c4_4968tris --workload c4 --spp 256 --c4-subdivide 0 --no-bunny
+run c1 --workload c1 --spp 128 --no-side &&
+run c3 --workload c3 --spp 128 --no-side &&
+run c4 --workload c4 --spp 256 --no-side &&
+run c5 --workload c5 --spp 128 --no-side &&
+run c4_4968tris --workload c4 --spp 256 --c4-subdivide 0 --no-side
