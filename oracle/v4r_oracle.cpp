@@ -1052,7 +1052,6 @@ void render_pass_packets(const v4r_scene_desc *s, uint64_t seed, uint32_t pass, 
         accum[3 * (size_t)pixel + 1] += c.y;
         accum[3 * (size_t)pixel + 2] += c.z;
     };
-    for (auto &c : counters) c.paths += 0;
     counters[0].paths += npix;
     std::vector<Closest> found;
     struct Order {
@@ -1145,8 +1144,10 @@ extern "C" {
 const char *v4o_last_error(void) { return g_error.c_str(); }
 
 // Adds n_passes full-image passes into accum (H*W*3 floats, row 0 = top).  mode 0 = the
-// reference's candidate-set traversal, 1 = the device's ordered traversal.  pixel_stride > 1
-// renders only pixels whose index is a multiple of it (for strided work counts).
+// reference's candidate-set traversal, one path at a time; 1 = the device's ordered traversal;
+// 2 = the reference's breadth-first pass with its 8-lane packets (render_pass_packets).
+// pixel_stride > 1 renders only pixels whose index is a multiple of it (for strided work counts;
+// modes 0 and 1).
 int v4o_render(const v4r_scene_desc *s, uint64_t seed, uint32_t first_pass, uint32_t pass_stride, uint32_t n_passes,
                float *accum, int n_threads, uint32_t pixel_stride, int mode, v4r_stats *stats) {
     if (int rc = validate(s)) return rc;
@@ -1163,6 +1164,22 @@ int v4o_render(const v4r_scene_desc *s, uint64_t seed, uint32_t first_pass, uint
     std::atomic<uint32_t> next{0};
     const uint32_t chunk = 256;
     std::vector<Counters> counters((size_t)n_threads);
+    auto report = [&]() {
+        if (!stats) return;
+        Counters total;
+        for (auto &c : counters) total.add(c);
+        stats->segments = total.segments;
+        stats->nodes = total.nodes;
+        stats->prims = total.prims;
+        stats->paths = total.paths;
+        stats->shaded = total.shaded;
+        stats->texel_fetches = total.texels;
+    };
+    if (mode == 2) {  // the reference's packets: whole passes, breadth first (pixel_stride does not apply)
+        for (uint32_t k = 0; k < n_passes; ++k) render_pass_packets(s, seed, first_pass + k * pass_stride, accum, n_threads, counters);
+        report();
+        return V4R_OK;
+    }
     WideTree wide;
     if (mode == 1) wide = build_wide(s);
     auto worker = [&](int tid) {
@@ -1188,16 +1205,7 @@ int v4o_render(const v4r_scene_desc *s, uint64_t seed, uint32_t first_pass, uint
     for (int t = 1; t < n_threads; ++t) threads.emplace_back(worker, t);
     worker(0);
     for (auto &t : threads) t.join();
-    if (stats) {
-        Counters total;
-        for (auto &c : counters) total.add(c);
-        stats->segments = total.segments;
-        stats->nodes = total.nodes;
-        stats->prims = total.prims;
-        stats->paths = total.paths;
-        stats->shaded = total.shaded;
-        stats->texel_fetches = total.texels;
-    }
+    report();
     return V4R_OK;
 }
 
