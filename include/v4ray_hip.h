@@ -239,6 +239,22 @@ int v4r_render(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_t pas
 int v4r_render_rows(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_t pass_stride, uint32_t n_passes, uint32_t row0,
                     uint32_t n_rows);
 
+/* v4r_render for callers that cannot allocate device memory: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  It has no counterpart in the reference.  Same arguments, same passes, same
+ * random streams and the same accumulator as v4r_render -- the image is bit-identical -- but the wavefront queues,
+ * segment counters and stack-spill slab live in a V4R_NOALLOC_SCRATCH_BYTES array that is part of the library's
+ * device image (every GPU the library runs on holds it until the process ends), and the call makes no hipMalloc,
+ * hipFree or other allocating call, creates no event or stream, and launches on the renderer's public stream
+ * only.  Limit: one pass (width x height paths) must fit the path slots the scratch has left after the scene's
+ * stack-spill slab and segment counters -- about 300 000 for a shallow tree, about 200 000 for the 79 488-triangle
+ * bunny; larger images, and scenes whose tree is too deep, get V4R_E_LIMIT with the numbers in v4r_last_error().
+ * Passes run in batches of scratch_slots / (width x height).  The scratch is shared by every renderer on the same
+ * GPU and keeps the previous call's contents (the call clears the counters it needs at zero): calls that overlap
+ * on one GPU -- two handles on different streams or threads -- race; serialise them. */
+#define V4R_NOALLOC_SCRATCH_BYTES (48u << 20)
+int v4r_render_noalloc(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_t pass_stride,
+                       uint32_t n_passes);
+
 /* Use caller-owned device memory (H*W*3 floats, e.g. a framework tensor that a collective will
  * reduce) as the accumulator from now on; NULL restores the renderer's own buffer.  The buffer is
  * not cleared.  No counterpart in the reference (its accumulator is the RwLock'd Vec of

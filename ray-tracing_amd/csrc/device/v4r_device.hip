@@ -35,6 +35,12 @@
 
 using namespace v4r;
 
+// Scratch of v4r_render_noalloc: the wavefront queues, segment counters and stack-spill slab of one small batch,
+// in a file-scope device array instead of hipMalloc'd memory.  Every GPU the library runs on holds its own copy
+// (at its own address) until the process ends; host code reaches it only through the per-device pointer that
+// scratch_of_device() obtains once with hipGetSymbolAddress.
+static __device__ __align__(256) unsigned char scratch[V4R_NOALLOC_SCRATCH_BYTES];
+
 namespace {
 
 constexpr int BLOCK = 256;
@@ -750,6 +756,7 @@ struct Pipe {
     hipEvent_t done = nullptr;  // recorded after the pipeline's latest k_resolve
     bool used = false;
     std::vector<void *> allocations;  // the queues of Q, sized for Q.cap path slots
+    uint32_t grid_trace = 0, grid_tail = 0;  // workgroups of its traversal launches (the spill slab has one column per thread)
 };
 
 struct v4r_renderer {
@@ -790,6 +797,8 @@ struct v4r_renderer {
     uint32_t tile_passes_log2 = 4;  // passes per wave tile of the camera-ray order (see ray_order)
     size_t ctr_bytes = 0;
     uint32_t max_depth = 0, spill_depth = 0;
+    unsigned char *scratch_ptr = nullptr;  // this device's copy of `scratch`
+    Pipe noalloc;                          // queues carved out of it (Q.cap = 0: the scene does not fit), on the public stream
 
     template <class T>
     int alloc(T **out, size_t count) {
@@ -1258,7 +1267,62 @@ int ensure_pipe(v4r_renderer *r, Pipe &pipe, size_t need) {
     Q.spill_stride = (size_t)r->grid_trace * BLOCK;
     if (int rc = alloc(&Q.spill, Q.spill_stride * std::max(r->spill_depth, 1u))) return rc;
     Q.cap = (uint32_t)need;
+    pipe.grid_trace = r->grid_trace;
+    pipe.grid_tail = r->grid_tail;
     return V4R_OK;
+}
+
+// The address of this device's copy of `scratch` (the device must be current).  The array's name is a host-side
+// handle, not a device address: only the pointer returned here may be handed to kernels or memsets.
+int scratch_of_device(int device, unsigned char **out) {
+    static std::mutex mu;
+    static std::vector<unsigned char *> known;
+    std::lock_guard<std::mutex> hold(mu);
+    if ((size_t)device >= known.size()) known.resize((size_t)device + 1, nullptr);
+    if (!known[device]) {
+        void *p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return set_error(V4R_E_HIP, "hipGetSymbolAddress returned a NULL scratch address");
+        known[device] = (unsigned char *)p;
+    }
+    *out = known[device];
+    return V4R_OK;
+}
+
+// Lay the queues of one batch pipeline out inside the scratch array: the stack-spill slab of a reduced traversal
+// grid, the segment counters, then as many path slots as the rest holds.  Leaves Q.cap = 0 when the scene's tree is
+// too deep or its depth budget too long for anything to fit.
+void carve_noalloc(v4r_renderer *r, int n_cu) {
+    Pipe &pipe = r->noalloc;
+    Queues &Q = pipe.Q;
+    Q = Queues{};
+    pipe.grid_trace = std::min<uint32_t>(r->grid_trace, (uint32_t)n_cu);
+    pipe.grid_tail = std::min<uint32_t>(r->grid_tail, pipe.grid_trace);
+    size_t off = 0;
+    auto take = [&](auto **out, size_t count) {
+        size_t bytes = (count * sizeof(**out) + 255) & ~(size_t)255;
+        if (off + bytes > (size_t)V4R_NOALLOC_SCRATCH_BYTES) return false;
+        *out = (std::remove_reference_t<decltype(**out)> *)(r->scratch_ptr + off);
+        off += bytes;
+        return true;
+    };
+    Q.spill_stride = (size_t)pipe.grid_trace * BLOCK;
+    if (!take(&Q.spill, Q.spill_stride * std::max(r->spill_depth, 1u))) return;
+    if (!take(&Q.ctr, (size_t)r->max_depth + 1)) return;
+    // per path slot: two ray queues of three 16-byte columns, the hit record, the radiance slot, the given-up index
+    // and one index per material class
+    const size_t per_slot = 2 * 3 * sizeof(float4) + 2 * sizeof(float4) + (1 + CLS_COUNT) * sizeof(uint32_t);
+    size_t cap = ((size_t)V4R_NOALLOC_SCRATCH_BYTES - off) / per_slot;
+    cap = cap > 4096 ? (cap - 4096) & ~(size_t)63 : 0;  // room for the 256-byte alignment of each of the 15 arrays
+    if (cap == 0) return;
+    bool ok = true;
+    for (int p = 0; p < 2; ++p)
+        for (int c = 0; c < 3; ++c) ok = ok && take(&Q.ray[p][c], cap);
+    for (int k = 0; k < CLS_COUNT; ++k) ok = ok && take(&Q.hit[k], cap);
+    ok = ok && take(&Q.hitd, cap) && take(&Q.given_up, cap) && take(&Q.rad, cap);
+    if (!ok) return;
+    Q.stats = r->stats;
+    Q.cap = (uint32_t)cap;
 }
 
 int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
@@ -1419,6 +1483,11 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     // Queues are sized by the jobs that arrive (ensure_pipe): pipeline 0 starts with room for one pass,
     // which also gives v4r_trace_rays its stack spill slab.
     if (int rc = ensure_pipe(r, r->pipes[0], r->npix)) return rc;
+    // v4r_render_noalloc: this device's scratch array, carved into one more pipeline that runs on the public stream
+    if (int rc = scratch_of_device(r->device, &r->scratch_ptr)) return rc;
+    r->noalloc.stream = r->stream;
+    HIP_TRY(hipEventCreateWithFlags(&r->noalloc.done, hipEventDisableTiming));
+    carve_noalloc(r, n_cu);
 
     if (int rc = r->alloc(&r->accum_own, (size_t)r->npix * 3)) return rc;
     HIP_TRY(hipMemset(r->accum_own, 0, (size_t)r->npix * 3 * sizeof(float)));
@@ -1431,7 +1500,7 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
 // Instantiations of k_trace: work counters x media mode x (segment 0 generates its camera rays) x (second launch).
 template <bool COUNT, int MEDIA, bool PRIMARY>
 uint32_t launch_trace_as(v4r_renderer *r, Pipe &pipe, uint32_t seg, const PrimaryArgs &A) {
-    dim3 grid(r->grid_trace), block(BLOCK);
+    dim3 grid(pipe.grid_trace), block(BLOCK);
     constexpr int R = TRACE_RAYS_PER_THREAD;
     // the first segments hold nearly all rays: there a wave gives its last few rays up to a second launch
     uint32_t give_up = seg < r->give_up_segments ? r->give_up_lanes : 0u;
@@ -1475,7 +1544,7 @@ uint32_t launch_shade(v4r_renderer *r, Pipe &pipe, uint32_t seg) {
 
 template <bool COUNT, int MEDIA>
 void launch_tail_as(v4r_renderer *r, Pipe &pipe, uint32_t seg) {
-    dim3 grid(r->grid_tail), block(BLOCK);
+    dim3 grid(pipe.grid_tail), block(BLOCK);
     if (r->any_noise) hipLaunchKernelGGL((k_tail<COUNT, MEDIA, true>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg);
     else hipLaunchKernelGGL((k_tail<COUNT, MEDIA, false>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg);
 }
@@ -1493,7 +1562,7 @@ void launch_tail(v4r_renderer *r, Pipe &pipe, uint32_t seg) {
 }
 
 int run_batch(v4r_renderer *r, Pipe &pipe, uint64_t seed, uint32_t first_pass, uint32_t pass_stride, uint32_t n_batch_passes, uint32_t row0,
-              uint32_t n_rows) {
+              uint32_t n_rows, bool may_profile = true) {
     const uint32_t band_pix = n_rows * r->S.width, band_offset = row0 * r->S.width;
     uint32_t n_paths = n_batch_passes * band_pix;
     HIP_TRY(hipMemsetAsync(pipe.Q.ctr, 0, r->ctr_bytes, pipe.stream));
@@ -1516,7 +1585,7 @@ int run_batch(v4r_renderer *r, Pipe &pipe, uint64_t seed, uint32_t first_pass, u
     // v4r_profile_*: a pair of HIP events on this pipeline's stream around a group of launches
     auto bracket_begin = [&](int group, v4r_renderer::EventPair *&pair) -> int {
         pair = nullptr;
-        if (!r->profiling || (r->profiling == 1 && group != V4R_PROFILE_TRACE)) return V4R_OK;
+        if (!may_profile || !r->profiling || (r->profiling == 1 && group != V4R_PROFILE_TRACE)) return V4R_OK;
         if (r->ev_used == r->ev_pool.size()) {
             v4r_renderer::EventPair e{};
             HIP_TRY(hipEventCreate(&e.start));
@@ -1623,6 +1692,7 @@ void v4r_renderer_destroy(v4r_renderer *r) {
     if (r->stream) (void)hipStreamDestroy(r->stream);
     for (auto &p : r->pipes)
         if (p.done) (void)hipEventDestroy(p.done);
+    if (r->noalloc.done) (void)hipEventDestroy(r->noalloc.done);
     if (r->fork) (void)hipEventDestroy(r->fork);
     for (auto &p : r->pipes)
         for (void *q : p.allocations) (void)hipFree(q);
@@ -1675,6 +1745,32 @@ int v4r_render_rows(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_
 int v4r_render(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_t pass_stride, uint32_t n_passes) {
     if (!r) return set_error(V4R_E_INVALID, "NULL renderer");
     return v4r_render_rows(r, seed, first_pass, pass_stride, n_passes, 0, r->S.height);
+}
+
+int v4r_render_noalloc(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_t pass_stride, uint32_t n_passes) {
+    if (!r) return set_error(V4R_E_INVALID, "NULL renderer");
+    std::lock_guard<std::recursive_mutex> hold(r->mu);
+    Pipe &pipe = r->noalloc;
+    if (pipe.Q.cap == 0)
+        return set_error(V4R_E_LIMIT, "v4r_render_noalloc: the scene's traversal stack and depth budget leave no room for path slots in the " +
+                                          std::to_string(V4R_NOALLOC_SCRATCH_BYTES >> 20) + " MiB scratch");
+    if (r->npix > pipe.Q.cap)
+        return set_error(V4R_E_LIMIT, "v4r_render_noalloc: one pass of " + std::to_string(r->S.width) + " x " + std::to_string(r->S.height) + " = " +
+                                          std::to_string(r->npix) + " paths exceeds the " + std::to_string(pipe.Q.cap) +
+                                          " path slots of the scratch for this scene (use v4r_render)");
+    if (pass_stride == 0) pass_stride = 1;
+    HIP_TRY(hipSetDevice(r->device));
+    uint32_t batch = std::min<uint32_t>(pipe.Q.cap / r->npix, 4096u);
+    if (batch >= 16u) batch &= ~15u;
+    // One pipeline on the public stream: batches run one after the other, ordered after whatever the handle queued
+    // before (v4r_render ends by joining its pipelines into this stream) and before whatever it queues next.
+    for (uint32_t done = 0; done < n_passes;) {
+        uint32_t nb = std::min(batch, n_passes - done);
+        if (int rc = run_batch(r, pipe, seed, first_pass + done * pass_stride, pass_stride, nb, 0, r->S.height, false)) return rc;
+        done += nb;
+    }
+    r->n_passes += n_passes;
+    return V4R_OK;
 }
 
 int v4r_accum_bind(v4r_renderer *r, float *device_hwc) {

@@ -538,6 +538,12 @@ class Renderer:
             check_dev(device_lib().v4r_render_rows(self._h, seed, int(first_pass), int(pass_stride), int(n_passes),
                                                    int(rows[0]), int(rows[1])))
 
+    def render_passes_noalloc(self, n_passes: int, first_pass: int = 0, pass_stride: int = 1, seed: Optional[int] = None) -> None:
+        """render_passes through the entry point that allocates nothing (queues in the library's static device scratch);
+        raises V4RayError (V4R_E_LIMIT) when one pass of the image does not fit it."""
+        seed = self.seed if seed is None else int(seed)
+        check_dev(device_lib().v4r_render_noalloc(self._h, seed, int(first_pass), int(pass_stride), int(n_passes)))
+
     def clear(self) -> None:
         check_dev(device_lib().v4r_accum_clear(self._h))
 

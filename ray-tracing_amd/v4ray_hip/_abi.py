@@ -183,7 +183,7 @@ DEVICE_SYMBOLS = [
     "v4r_abi_version", "v4r_last_error", "v4r_renderer_create", "v4r_renderer_destroy", "v4r_render", "v4r_render_rows",
     "v4r_accum_bind", "v4r_reduce", "v4r_accum_clear", "v4r_accum_read", "v4r_accum_write", "v4r_accum_device", "v4r_tonemap_u8",
     "v4r_trace_primary", "v4r_trace_rays", "v4r_stats_enable", "v4r_stats_read", "v4r_synchronize",
-    "v4r_stream", "v4r_pass_count", "v4r_profile_enable", "v4r_profile_read", "v4r_profile_read_groups",
+    "v4r_stream", "v4r_pass_count", "v4r_profile_enable", "v4r_profile_read", "v4r_profile_read_groups", "v4r_render_noalloc",
 ]
 
 
@@ -207,6 +207,7 @@ def device_lib():
     _sig(lib.v4r_renderer_destroy, None, vp)
     _sig(lib.v4r_render, i32, vp, u64, u32, u32, u32)
     _sig(lib.v4r_render_rows, i32, vp, u64, u32, u32, u32, u32, u32)
+    _sig(lib.v4r_render_noalloc, i32, vp, u64, u32, u32, u32)
     _sig(lib.v4r_accum_bind, i32, vp, vp)
     _sig(lib.v4r_reduce, i32, vp, vp, i32)
     _sig(lib.v4r_accum_clear, i32, vp)
