@@ -142,9 +142,19 @@ typedef struct v4r_camera {
 } v4r_camera;
 
 /* Scene flags. */
-#define V4R_FLAG_BOUNDED_LIGHT_PDF 0x1u /* rect/triangle light pdf is 0 for directions that miss the
-                                           light (textbook); default off = the reference's packet
-                                           behaviour (aa_rect.rs:158-179, triangle.rs:110-131)   */
+/* The pdf value of a rectangle / triangle light for a direction that misses it.  In the reference a SIMD lane gets
+ * the un-clipped plane density when some lane of its 8-ray packet hits the light and 0 when none does
+ * (aa_rect.rs:158-179, triangle.rs:110-131); packets hold rays of one pass and recursion level that hit the same
+ * shape (renderer.rs:189-217).  Default (no flag): that rule in expectation -- the size of the ray's packet follows
+ * from the number of rays of its pass and level that hit its shape (counted on the device for the first
+ * V4R_PACKET_COUNTED_LEVELS levels), and "some packet mate hits the light" is drawn with the probability it has in
+ * such a packet.  V4R_FLAG_PLANE_LIGHT_PDF: the plane density always (what a lane of a full packet nearly always
+ * gets; a pure function of the ray, used for per-pixel comparisons).  V4R_FLAG_BOUNDED_LIGHT_PDF: 0 for every
+ * direction that misses the light (the textbook density). */
+#define V4R_FLAG_BOUNDED_LIGHT_PDF 0x1u
+#define V4R_FLAG_PLANE_LIGHT_PDF 0x4u
+#define V4R_PACKET_COUNTED_LEVELS 8u
+#define V4R_PACKET_MANY_RAYS 256u
 
 #define V4R_FLAG_KEEP_HOST_BVH 0x2u     /* traverse the topology of `nodes` as given (widened 2 -> 4);
                                            default off = the device library re-splits the same leaf

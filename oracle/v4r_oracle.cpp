@@ -109,7 +109,9 @@ enum {
     DIM_LENS_R = 2,
     DIM_LENS_THETA = 3,
     DIM_TIME = 4,
-    DIM_SCATTER = 8,  // 8..15: material / pdf sampling at the end of the segment
+    DIM_SCATTER = 8,       // 8..13: material / pdf sampling at the end of the segment
+    DIM_PACKET_SLOT = 14,  // packet-statistics rule: is the ray in its shape's last, partial packet
+    DIM_PACKET_ANY = 16,   // 16..31: packet-statistics rule, + (light index & 15): does a packet mate hit that light
     DIM_MEDIUM = 32   // 32..63: constant-medium free-path draw, + (primitive index & 31)
 };
 
@@ -144,6 +146,7 @@ struct Ctx {
     const v4r_scene_desc *s;
     uint32_t seg_key = 0;  // key of the segment being traced / shaded
     uint32_t packet_light = 0xFFFFFFFFu;  // packet mode: the light index HittableGroup::generate drew for the whole packet
+    uint32_t packet_n = 0;  // packet-statistics rule (mode 3): rays of this pass and level whose closest hit is the shape being shaded; 0 = rule off
     Counters cnt;
     const WideTree *wide = nullptr;  // mode 1 only
 };
@@ -821,6 +824,82 @@ float lights_value(Ctx &ctx, V3 origin, V3 dir) {
     return sum;
 }
 
+// The packet-statistics rule (mode 3; the device's default): what the reference's 8-lane packets do to the light pdf,
+// in expectation, without forming the packets.  In the reference a lane whose direction misses a rectangle or triangle
+// light still gets the un-clipped plane density when some lane of its packet hits that light, and 0 when none does
+// (aa_rect.rs:158-179, triangle.rs:110-131).  A packet holds rays of one pass and level that hit the same shape, so:
+//   * k, the size of the ray's packet: the shape receives `n` rays; they are cut into packets of 8, the last one
+//     holding n mod 8; the ray sits in that last packet with probability (n mod 8) / n (one uniform draw);
+//   * each of the k - 1 mates samples the light list half of the time (mixture.rs:27-32) -- the light the packet
+//     drew, `li`, whose sampled direction hits it -- and a cosine direction otherwise, which hits light L with
+//     probability h_L (its cosine-weighted solid angle, estimated from its centre, area and normal);
+//   * so no mate hits L with probability (1 - (0.5 [L == li] + 0.5 h_L))^(k-1); one more uniform draw per light
+//     decides, and the lane gets 0 or the plane density accordingly.  Sphere lights mask per lane (sphere.rs:107-130).
+struct PacketRule {
+    static constexpr uint32_t COUNTED_LEVELS = V4R_PACKET_COUNTED_LEVELS;  // levels whose per-shape ray counts are taken; deeper levels reuse the last
+    static constexpr uint32_t MANY_RAYS = V4R_PACKET_MANY_RAYS;            // a shape with this many rays or more: every packet counts as full
+};
+
+// h_L of the rule above, for an untransformed rectangle or triangle light seen from surface point p with normal n.
+float light_cosine_share(const v4r_prim &pr, V3 p, V3 n) {
+    if (pr.xform != V4R_NO_XFORM) return 0.0f;
+    V3 centre, ln;
+    float area;
+    uint32_t kind = pr.type & V4R_PRIM_TYPE_MASK;
+    if (kind == V4R_PRIM_TRIANGLE) {
+        V3 e12 = v3(pr.f + 3), e13 = v3(pr.f + 6), c = cross(e12, e13);
+        centre = v3(pr.f) + (e12 + e13) * (1.0f / 3.0f);
+        float len = norm(c);
+        ln = c / len;
+        area = len * 0.5f;
+    } else if (kind >= V4R_PRIM_XY_RECT && kind <= V4R_PRIM_ZX_RECT) {
+        int ia, ib, ik;
+        rect_axes(pr.type, ia, ib, ik);
+        float c[3];
+        c[ia] = 0.5f * (pr.f[0] + pr.f[1]);
+        c[ib] = 0.5f * (pr.f[2] + pr.f[3]);
+        c[ik] = pr.f[4];
+        centre = v3(c);
+        ln = axis_vec(ik, 1.0f);
+        area = (pr.f[1] - pr.f[0]) * (pr.f[3] - pr.f[2]);
+    } else {
+        return 0.0f;
+    }
+    V3 w = centre - p;
+    float d2 = norm2(w), d = std::sqrt(d2);
+    float cos_l = std::fabs(dot(w, ln)) / d, cos_p = dot(w, n) / d;
+    if (!(cos_p > 0.0f)) return 0.0f;
+    float h = area * cos_l * cos_p / (PI * d2);
+    return h < 1.0f ? h : 1.0f;  // NaN (p at the centre) -> 1
+}
+
+// HittableGroup::value (group.rs:76-89) under the packet-statistics rule: `n` rays hit this shape, `li` is the light
+// index the ray drew, `normal` the shading normal at `origin`.
+float lights_value_stat(Ctx &ctx, V3 origin, V3 normal, V3 dir, uint32_t li, uint32_t n, uint32_t key) {
+    const v4r_scene_desc *s = ctx.s;
+    uint32_t k = 8;
+    if (n < 8) {
+        k = n < 1 ? 1 : n;
+    } else if (n < PacketRule::MANY_RAYS) {
+        uint32_t r = n % 8u;
+        if (r != 0u && draw(key, DIM_PACKET_SLOT) * (float)n < (float)r) k = r;
+    }
+    const float weight = 1.0f / (float)s->n_lights;
+    float sum = 0.0f;
+    for (uint32_t l = 0; l < s->n_lights; ++l) {
+        bool hit, per_lane;
+        float density = light_probe(ctx, s->lights[l], origin, dir, hit, per_lane);
+        if (!per_lane && !hit) {
+            float q = 1.0f - (0.5f * (l == li ? 1.0f : 0.0f) + 0.5f * light_cosine_share(s->prims[s->lights[l]], origin, normal));
+            float p_none = 1.0f;
+            for (uint32_t m = 1; m < k; ++m) p_none = p_none * q;
+            if (!(draw(key, DIM_PACKET_ANY + (l & 15u)) >= p_none)) density = 0.0f;
+        }
+        sum += weight * density;
+    }
+    return sum;
+}
+
 // ---- materials ----------------------------------------------------------------------------------
 inline V3 reflect(V3 v, V3 n) { return v - n * (dot(v, n) * 2.0f); }  // material/mod.rs:47-52
 inline V3 refract(V3 uv, V3 n, float etai_over_etat) {               // material/mod.rs:54-63
@@ -877,7 +956,8 @@ Scatter shade(Ctx &ctx, uint32_t prim_index, const Ray &ray, const Hit &h) {
                     out.pdf_v = pdf_v;
                     return out;
                 }
-                float mix_v = 0.5f * lights_value(ctx, h.p, dir) + 0.5f * pdf_v;  // pdf/mixture.rs:22-25
+                float light_v = ctx.packet_n != 0 ? lights_value_stat(ctx, h.p, h.normal, dir, li, ctx.packet_n, key) : lights_value(ctx, h.p, dir);
+                float mix_v = 0.5f * light_v + 0.5f * pdf_v;  // pdf/mixture.rs:22-25
                 out.coef = attenuation * pdf_v / mix_v;
             } else {  // renderer.rs:245-255
                 out.dir = cosine_generate(h.normal, draw(key, DIM_SCATTER + 4), draw(key, DIM_SCATTER + 5));
@@ -1038,8 +1118,13 @@ void parallel_for(uint32_t n, int n_threads, F body) {  // body(begin, end, thre
     for (auto &t : threads) t.join();
 }
 
-void render_pass_packets(const v4r_scene_desc *s, uint64_t seed, uint32_t pass, float *accum, int n_threads, std::vector<Counters> &counters) {
+// rule 2: the reference's packets; rule 3: the packet-statistics rule (per-ray shading, per-shape ray counts of the level)
+// trace_mode: 0 = the reference's candidate-set traversal, 1 = the device's ordered traversal of `wide` (same hits).
+void render_pass_packets(const v4r_scene_desc *s, uint64_t seed, uint32_t pass, float *accum, int n_threads, std::vector<Counters> &counters,
+                         int rule, int trace_mode, const WideTree *wide) {
     const uint32_t npix = s->width * s->height;
+    std::vector<uint32_t> shape_rays;  // rule 3: rays of this level per closest-hit shape
+    if (rule == 3) shape_rays.assign(s->n_prims, 0u);
     std::vector<LevelRay> cur(npix), next;
     parallel_for(npix, n_threads, [&](uint32_t b, uint32_t e, int) {
         for (uint32_t pix = b; pix < e; ++pix) {
@@ -1065,9 +1150,10 @@ void render_pass_packets(const v4r_scene_desc *s, uint64_t seed, uint32_t pass, 
         found.assign(n, Closest{});
         parallel_for(n, n_threads, [&](uint32_t b, uint32_t e, int tid) {
             Ctx ctx{s};
+            ctx.wide = wide;
             for (uint32_t i = b; i < e; ++i) {
                 ctx.seg_key = segment_key(cur[i].pk, seg);
-                found[i] = trace(ctx, cur[i].ray, 0);
+                found[i] = trace(ctx, cur[i].ray, trace_mode);
             }
             counters[(size_t)tid].add(ctx.cnt);
         });
@@ -1076,19 +1162,37 @@ void render_pass_packets(const v4r_scene_desc *s, uint64_t seed, uint32_t pass, 
             if (!found[i].hit.mask) add(cur[i].pixel, cur[i].thr * v3(s->background));  // renderer.rs:184
             else order.push_back({found[i].prim, found[i].first, i});
         }
-        std::sort(order.begin(), order.end(), [](const Order &a, const Order &b) {
+        if (rule == 3) {
+            if (seg < PacketRule::COUNTED_LEVELS) {  // deeper levels reuse the counts of the last counted one
+                std::fill(shape_rays.begin(), shape_rays.end(), 0u);
+                for (const Order &o : order) shape_rays[o.shape]++;
+            }
+            scattered.assign(order.size(), Scatter{});
+            parallel_for((uint32_t)order.size(), n_threads, [&](uint32_t b, uint32_t e, int tid) {
+                Ctx ctx{s};
+                for (uint32_t q = b; q < e; ++q) {
+                    const LevelRay &r = cur[order[q].ray];
+                    ctx.seg_key = segment_key(r.pk, seg);
+                    uint32_t n = shape_rays[order[q].shape];
+                    ctx.packet_n = n < 1u ? 1u : n;
+                    scattered[q] = shade(ctx, order[q].shape, r.ray, found[order[q].ray].hit);
+                }
+                counters[(size_t)tid].add(ctx.cnt);
+            });
+        }
+        if (rule == 2) std::sort(order.begin(), order.end(), [](const Order &a, const Order &b) {
             if (a.shape != b.shape) return a.shape < b.shape;
             if (a.first != b.first) return a.first < b.first;
             return a.ray < b.ray;
         });
         packet_start.clear();
-        for (size_t k = 0; k < order.size();) {
+        for (size_t k = 0; rule == 2 && k < order.size();) {
             size_t end = k;
             while (end < order.size() && order[end].shape == order[k].shape) ++end;
             for (size_t q = k; q < end; q += LANES) packet_start.push_back((uint32_t)q);
             k = end;
         }
-        scattered.assign(order.size(), Scatter{});
+        if (rule == 2) scattered.assign(order.size(), Scatter{});
         parallel_for((uint32_t)packet_start.size(), n_threads, [&](uint32_t b, uint32_t e, int tid) {
             Ctx ctx{s};
             for (uint32_t p = b; p < e; ++p) {
@@ -1144,8 +1248,10 @@ extern "C" {
 const char *v4o_last_error(void) { return g_error.c_str(); }
 
 // Adds n_passes full-image passes into accum (H*W*3 floats, row 0 = top).  mode 0 = the
-// reference's candidate-set traversal, one path at a time; 1 = the device's ordered traversal;
-// 2 = the reference's breadth-first pass with its 8-lane packets (render_pass_packets).
+// reference's candidate-set traversal; 1 = the device's ordered traversal; both with the light pdf the scene's
+// flags select, like the device (no flag: the packet-statistics rule, lights_value_stat);
+// 2 = the reference's breadth-first pass with its 8-lane packets (render_pass_packets); 3 = the
+// packet-statistics rule whatever the flags.
 // pixel_stride > 1 renders only pixels whose index is a multiple of it (for strided work counts;
 // modes 0 and 1).
 int v4o_render(const v4r_scene_desc *s, uint64_t seed, uint32_t first_pass, uint32_t pass_stride, uint32_t n_passes,
@@ -1175,13 +1281,19 @@ int v4o_render(const v4r_scene_desc *s, uint64_t seed, uint32_t first_pass, uint
         stats->shaded = total.shaded;
         stats->texel_fetches = total.texels;
     };
-    if (mode == 2) {  // the reference's packets: whole passes, breadth first (pixel_stride does not apply)
-        for (uint32_t k = 0; k < n_passes; ++k) render_pass_packets(s, seed, first_pass + k * pass_stride, accum, n_threads, counters);
+    WideTree wide;
+    if (mode == 1) wide = build_wide(s);
+    // Scenes with lights and neither light-pdf flag follow the packet-statistics rule, which needs the per-shape ray
+    // counts of whole passes: modes 0 and 1 then run the breadth-first pass too (a strided render, which only serves
+    // work counts, keeps the per-path loop and the plane density: the paths are the same, only their weights differ).
+    const bool packet_rule = s->n_lights != 0 && !(s->flags & (V4R_FLAG_BOUNDED_LIGHT_PDF | V4R_FLAG_PLANE_LIGHT_PDF));
+    if (mode == 2 || mode == 3 || (packet_rule && pixel_stride == 1)) {  // whole passes, breadth first
+        const int rule = mode == 2 ? 2 : 3;
+        for (uint32_t k = 0; k < n_passes; ++k)
+            render_pass_packets(s, seed, first_pass + k * pass_stride, accum, n_threads, counters, rule, mode == 1 ? 1 : 0, &wide);
         report();
         return V4R_OK;
     }
-    WideTree wide;
-    if (mode == 1) wide = build_wide(s);
     auto worker = [&](int tid) {
         Ctx ctx{s};
         ctx.wide = &wide;

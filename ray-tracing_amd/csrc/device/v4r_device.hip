@@ -44,6 +44,9 @@ static __device__ __align__(256) unsigned char scratch[V4R_NOALLOC_SCRATCH_BYTES
 namespace {
 
 constexpr int BLOCK = 256;
+#ifndef V4R_COUNT_VARIANT
+#define V4R_COUNT_VARIANT 4
+#endif
 #ifndef V4R_TRACE_RAYS_PER_THREAD
 #define V4R_TRACE_RAYS_PER_THREAD 4
 #endif
@@ -60,7 +63,7 @@ struct SegCtr {
 static_assert(sizeof(SegCtr) == 64, "SegCtr is one 64-byte line");
 
 struct Queues {
-    float4 *ray[2][3];          // [segment parity][column]: {o.xyz,d.x} {d.yz,thr.rg} {thr.b,slot,k0,k1}
+    float4 *ray[2][3];          // [segment parity][column]: {o.xyz,d.x} {d.yz,slot,thr.r} {thr.gb,k0,k1}
     uint32_t *hit[CLS_COUNT];   // per shading class: the indices (into the ray queue of the segment) of the rays that hit it
     float4 *hitd;               // {t, prim, u, v} of ray i of the segment being traced
     uint32_t *given_up;         // indices of the rays whose wave gave them up (see traverse); traced by a second launch
@@ -68,8 +71,12 @@ struct Queues {
     SegCtr *ctr;                // [max_depth + 1]
     uint2 *spill;               // traversal stack overflow, [entry][global thread]
     unsigned long long *stats;  // segments, nodes, prims, paths, shaded, texel fetches, wave node steps, wave leaf steps
+    uint32_t *shape_rays;       // packet-statistics rule of the light pdf: [pass of the batch][primitive], the rays of the segment being
+                                // traced whose closest hit is that primitive (Lambertian shapes only), counted up to V4R_PACKET_MANY_RAYS
     uint32_t spill_stride;
     uint32_t cap;               // path slots per batch
+    uint32_t npix;              // pixels per pass of the batch being rendered (path slot = pass of the batch * npix + pixel)
+    uint32_t flags_offset;      // shape_rays[flags_offset + i] != 0: counter i has reached V4R_PACKET_MANY_RAYS and is no longer incremented
 };
 
 V4R_DEV uint32_t lane_id() { return threadIdx.x & 63u; }
@@ -87,15 +94,15 @@ struct PathState {
 
 V4R_DEV void store_ray(float4 *const col[3], uint32_t i, const PathState &p) {
     col[0][i] = make_float4(p.o.x, p.o.y, p.o.z, p.d.x);
-    col[1][i] = make_float4(p.d.y, p.d.z, p.thr.x, p.thr.y);
-    col[2][i] = make_float4(p.thr.z, __uint_as_float(p.slot), __uint_as_float(p.k0), __uint_as_float(p.k1));
+    col[1][i] = make_float4(p.d.y, p.d.z, __uint_as_float(p.slot), p.thr.x);
+    col[2][i] = make_float4(p.thr.y, p.thr.z, __uint_as_float(p.k0), __uint_as_float(p.k1));
 }
 V4R_DEV PathState unpack_ray(float4 a, float4 b, float4 c) {
     PathState p;
     p.o = v3(a.x, a.y, a.z);
     p.d = v3(a.w, b.x, b.y);
-    p.thr = v3(b.z, b.w, c.x);
-    p.slot = __float_as_uint(c.y);
+    p.thr = v3(b.w, c.x, c.y);
+    p.slot = __float_as_uint(b.z);
     p.k0 = __float_as_uint(c.z);
     p.k1 = __float_as_uint(c.w);
     return p;
@@ -230,7 +237,7 @@ V4R_DEV void stage_tree_top(const SceneDev &S, v4f *s_top, Stack &st) {
 // scenes and 46 % on the bunny scene, but its extra votes and low-occupancy set-up code made all but
 // the bunny scene 5-20 % slower, so rays are assigned statically.)
 #ifndef V4R_TRACE_MIN_WAVES
-#define V4R_TRACE_MIN_WAVES 1  // tuning hook: forcing 6 waves/SIMD (80 VGPRs) spills and is not faster
+#define V4R_TRACE_MIN_WAVES 5  // 94-98 VGPRs unforced; tuning hook: forcing 6 waves/SIMD (80 VGPRs) spills and is not faster
 #endif
 #ifndef V4R_TRACE_MIN_WAVES_PRIMARY
 #define V4R_TRACE_MIN_WAVES_PRIMARY 5  // 109-113 VGPRs unforced (4 waves/SIMD); at 96 with 32-40 B of scratch: C4 +1-2 %, others flat
@@ -268,7 +275,9 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
     SegCtr *ctr = Q.ctr + seg;
     const uint32_t n_in = second ? ctr->given_up : (PRIMARY ? A.n_paths : rays_in(Q, seg));
     float4 *const *rq = Q.ray[seg & 1u];
-    const uint32_t npix = A.npix;  // PRIMARY only
+    const uint32_t npix = A.npix;
+    // packet-statistics rule of the light pdf: the first levels count the rays that end on each Lambertian shape
+    const bool count_shape_rays = S.packet_rule != 0u && seg < V4R_PACKET_COUNTED_LEVELS;
     TraceCounters cnt;
     uint32_t n_traced = 0;
     bool started = false;
@@ -339,9 +348,26 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
                 } else if (active) {
                     if (COUNT) n_traced++;
                     if (best.prim != NO_PRIM) {
+                        // Packet-statistics rule of the light pdf: count the pass's rays per Lambertian shape they end on.  A
+                        // counter that reaches V4R_PACKET_MANY_RAYS raises its "full" flag and is left alone from then on
+                        // (walls would otherwise serialise the chip on a handful of addresses; from that count on the rule
+                        // treats every packet as full).  The flag is read and written with plain accesses: a stale 0 only
+                        // costs one more increment.  Its load is issued beside the primitive's class.
+                        uint32_t *n_rays = Q.shape_rays;
+                        uint32_t full = 1u;
+                        if (count_shape_rays) {
+                            uint32_t pass = PRIMARY ? pass_in_batch : __float_as_uint(rq[1][i].z) / npix;
+                            n_rays += (size_t)pass * S.n_prims + best.prim;
+                            full = n_rays[Q.flags_offset];
+                        }
                         uint32_t cls = S.prim_info[best.prim] >> 24;
                         Q.hitd[i] = make_float4(best.t, __uint_as_float(best.prim), best.u, best.v);
                         w = (cls << 16) | atomicAdd(&s_cnt[cls], 1u);
+#if V4R_COUNT_VARIANT == 4
+                        if (count_shape_rays && (cls == (uint32_t)CLS_LAMBERT || cls == (uint32_t)CLS_LAMBERT_NOISE) && full == 0u &&
+                            atomicAdd(n_rays, 1u) + 1u >= V4R_PACKET_MANY_RAYS)
+                            n_rays[Q.flags_offset] = 1u;
+#endif
                         if (PRIMARY) {
                             PathState p;
                             p.o = o;
@@ -355,7 +381,7 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
                         Q.rad[pass_in_batch * npix + pixel] = make_float4(S.bg[0], S.bg[1], S.bg[2], 0.0f);
                     } else {
                         float4 bb = rq[1][i], c = rq[2][i];
-                        Q.rad[__float_as_uint(c.y)] = make_float4(bb.z * S.bg[0], bb.w * S.bg[1], c.x * S.bg[2], 0.0f);
+                        Q.rad[__float_as_uint(bb.z)] = make_float4(bb.w * S.bg[0], c.x * S.bg[1], c.y * S.bg[2], 0.0f);
                     }
                 }
                 s_where[j * BLOCK + threadIdx.x] = w;
@@ -400,12 +426,16 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
 // (it met a light, or its depth budget is spent).
 // NOISE: some texture of the class's materials is (or contains) a Perlin noise texture.
 template <int CLS, bool NOISE>
-V4R_DEV bool shade_hit(const SceneDev &S, const PathState &p, float4 dcol, uint32_t seg, uint32_t &texel_fetches, PathState &q, float4 &rad) {
+V4R_DEV bool shade_hit(const SceneDev &S, const Queues &Q, const PathState &p, float4 dcol, uint32_t seg, uint32_t &texel_fetches, PathState &q, float4 &rad) {
     const float t = dcol.x;
     const uint32_t prim = __float_as_uint(dcol.y);
     // the material's parameters (metal, dielectric) or the record of its texture (the textured kinds)
     const uint4 rec0 = S.prim_shade[2 * (size_t)prim], rec1 = S.prim_shade[2 * (size_t)prim + 1];
     const uint32_t key = segment_key(p.k0, p.k1, seg);
+    // packet-statistics rule of the light pdf: the rays of the path's pass that ended on this shape at this level (k_trace
+    // counted them); fetched first, beside the records above
+    uint32_t n_rays = 0u;
+    if ((CLS == CLS_LAMBERT || CLS == CLS_LAMBERT_NOISE) && S.packet_rule) n_rays = Q.shape_rays[(size_t)(p.slot / Q.npix) * S.n_prims + prim];
     if (CLS == CLS_LIGHT) {  // material/diffuse_light.rs:19-22; scatter() is the default None
         HitD h = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, false);
         V3 e = texture_value<NOISE>(
@@ -440,7 +470,7 @@ V4R_DEV bool shade_hit(const SceneDev &S, const PathState &p, float4 dcol, uint3
             V3 d_light = light_generate(S, S.lights[li], h.p, draw(key, DIM_SCATTER + 2), draw(key, DIM_SCATTER + 3));
             dir = pick_light ? d_light : d_cos;
             float pdf_v = cosine_value(h.normal, dir);
-            float mix_v = 0.5f * lights_value(S, h.p, dir) + 0.5f * pdf_v;
+            float mix_v = 0.5f * lights_value(S, h.p, h.normal, dir, li, n_rays, key) + 0.5f * pdf_v;
             coef = attenuation * pdf_v / mix_v;
         } else {  // renderer.rs:245-255
             dir = d_cos;
@@ -528,7 +558,7 @@ __global__ __launch_bounds__(BLOCK, NOISE ? V4R_SHADE_MIN_WAVES_NOISE : 1) void 
         PathState q;
         float4 rad;
         uint32_t fetched = 0;
-        bool goes_on = shade_hit<CLS, NOISE>(S, p, dcol, seg, fetched, q, rad);
+        bool goes_on = shade_hit<CLS, NOISE>(S, Q, p, dcol, seg, fetched, q, rad);
         if (!valid) continue;  // a lane past the end of the queue shaded a copy of the last hit
         texel_fetches += fetched;
         if (goes_on) store_ray(out, out_base + i, q);  // hit i of this class -> ray out_base + i of the next segment
@@ -557,7 +587,7 @@ V4R_DEV void tail_shade(const SceneDev &S, const Queues &Q, uint32_t cls, float4
         PathState q;
         float4 rad;
         n_shaded++;
-        if (shade_hit<CLS, NOISE>(S, p, dcol, seg, texel_fetches, q, rad)) {
+        if (shade_hit<CLS, NOISE>(S, Q, p, dcol, seg, texel_fetches, q, rad)) {
             p = q;
         } else {
             Q.rad[p.slot] = rad;
@@ -756,6 +786,7 @@ struct Pipe {
     hipEvent_t done = nullptr;  // recorded after the pipeline's latest k_resolve
     bool used = false;
     std::vector<void *> allocations;  // the queues of Q, sized for Q.cap path slots
+    size_t count_passes = 0;          // passes Q.shape_rays has rows for
     uint32_t grid_trace = 0, grid_tail = 0;  // workgroups of its traversal launches (the spill slab has one column per thread)
 };
 
@@ -1230,12 +1261,21 @@ uint32_t collapse_to_wide(const v4r_scene_desc *d, const v4r_bvh_node *nodes, ui
     return depth;  // in wide nodes, root = 1
 }
 
-// Give `pipe` queues for at least `need` path slots.  Growing frees the old queues first (after the
+// Under the packet-statistics rule a batch keeps one ray counter per pass and primitive: bound that table to 128 MiB.
+uint32_t cap_counted_passes(const v4r_renderer *r, uint32_t passes) {
+    if (!r->S.packet_rule || r->S.n_prims == 0) return passes;
+    return std::max(1u, std::min<uint32_t>(passes, std::max(16u, (32u << 20) / r->S.n_prims)));
+}
+
+// Give `pipe` queues for at least `need` path slots (and ray counters for `n_passes` passes, see Queues::shape_rays).  Growing frees the old queues first (after the
 // pipeline has drained), so a renderer's footprint follows the largest batch it has been asked for:
 // ~384 B per slot with four material classes, i.e. 0.25 GB for one 800x800 pass and 12.7 GB for a 32 M batch.
-int ensure_pipe(v4r_renderer *r, Pipe &pipe, size_t need) {
+int ensure_pipe(v4r_renderer *r, Pipe &pipe, size_t need, size_t n_passes) {
     Queues &Q = pipe.Q;
-    if (Q.cap >= need && !pipe.allocations.empty()) return V4R_OK;
+    if (!r->S.packet_rule) n_passes = 0;
+    if (Q.cap >= need && pipe.count_passes >= n_passes && !pipe.allocations.empty()) return V4R_OK;
+    need = std::max<size_t>(need, Q.cap);
+    n_passes = std::max(n_passes, pipe.count_passes);
     HIP_TRY(hipStreamSynchronize(pipe.stream));
     for (void *p : pipe.allocations) (void)hipFree(p);
     pipe.allocations.clear();
@@ -1266,6 +1306,8 @@ int ensure_pipe(v4r_renderer *r, Pipe &pipe, size_t need) {
     Q.stats = r->stats;
     Q.spill_stride = (size_t)r->grid_trace * BLOCK;
     if (int rc = alloc(&Q.spill, Q.spill_stride * std::max(r->spill_depth, 1u))) return rc;
+    if (int rc = alloc(&Q.shape_rays, 2 * n_passes * r->S.n_prims)) return rc;  // counters, then their "full" flags
+    pipe.count_passes = n_passes;
     Q.cap = (uint32_t)need;
     pipe.grid_trace = r->grid_trace;
     pipe.grid_tail = r->grid_tail;
@@ -1292,6 +1334,7 @@ int scratch_of_device(int device, unsigned char **out) {
 // Lay the queues of one batch pipeline out inside the scratch array: the stack-spill slab of a reduced traversal
 // grid, the segment counters, then as many path slots as the rest holds.  Leaves Q.cap = 0 when the scene's tree is
 // too deep or its depth budget too long for anything to fit.
+constexpr uint32_t NOALLOC_COUNTED_PASSES = 16;
 void carve_noalloc(v4r_renderer *r, int n_cu) {
     Pipe &pipe = r->noalloc;
     Queues &Q = pipe.Q;
@@ -1309,6 +1352,10 @@ void carve_noalloc(v4r_renderer *r, int n_cu) {
     Q.spill_stride = (size_t)pipe.grid_trace * BLOCK;
     if (!take(&Q.spill, Q.spill_stride * std::max(r->spill_depth, 1u))) return;
     if (!take(&Q.ctr, (size_t)r->max_depth + 1)) return;
+    if (r->S.packet_rule) {  // ray counters of the packet-statistics rule, for batches of up to NOALLOC_COUNTED_PASSES passes
+        if (!take(&Q.shape_rays, 2 * (size_t)NOALLOC_COUNTED_PASSES * r->S.n_prims)) return;
+        pipe.count_passes = NOALLOC_COUNTED_PASSES;
+    }
     // per path slot: two ray queues of three 16-byte columns, the hit record, the radiance slot, the given-up index
     // and one index per material class
     const size_t per_slot = 2 * 3 * sizeof(float4) + 2 * sizeof(float4) + (1 + CLS_COUNT) * sizeof(uint32_t);
@@ -1418,6 +1465,7 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     S.n_prims = d->n_prims;
     S.n_lights = d->n_lights;
     S.flags = d->flags;
+    S.packet_rule = d->n_lights != 0 && !(d->flags & (V4R_FLAG_BOUNDED_LIGHT_PDF | V4R_FLAG_PLANE_LIGHT_PDF));
     std::memcpy(S.bg, d->background, sizeof S.bg);
     std::memcpy(S.env, d->environment, sizeof S.env);
     S.cam = d->camera;
@@ -1435,6 +1483,7 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     }
     r->batch_passes = (uint32_t)std::max<size_t>(1, std::min<size_t>(target / r->npix, 4096));
     if ((uint64_t)r->batch_passes * r->npix > 0x7FFFFFFFull) r->batch_passes = (uint32_t)(0x7FFFFFFFull / r->npix);
+    r->batch_passes = cap_counted_passes(r, r->batch_passes);
     if (r->batch_passes >= 16u) r->batch_passes &= ~15u;  // whole groups of passes for the tiled order of the camera rays
     uint32_t n_pipes = 3;
     if (const char *env = std::getenv("V4R_PIPES")) n_pipes = (uint32_t)std::max(1, std::min(4, std::atoi(env)));
@@ -1464,6 +1513,8 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     // Perlin code (3 waves/SIMD) only pay off later (C1 +1.5 % from 24, -3 % from 12)
     r->tail_segment = r->media_mode == MEDIA_IN_TREE || r->any_noise ? 24 : 12;
     if (const char *env = std::getenv("V4R_TAIL_SEGMENT")) r->tail_segment = (uint32_t)std::max(0, std::atoi(env));
+    // the tail kernel does not count rays per shape: under the packet-statistics rule it starts after the counted levels
+    if (S.packet_rule && r->tail_segment != 0) r->tail_segment = std::max(r->tail_segment, V4R_PACKET_COUNTED_LEVELS);
     // a ray's stack holds at most three entries per level of the wide tree above its current node
     uint32_t stack_max = 3u * wide_depth + 1u;
     uint32_t spill_depth = stack_max > (uint32_t)LDS_DEPTH ? stack_max - LDS_DEPTH : 0;
@@ -1482,7 +1533,7 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     }
     // Queues are sized by the jobs that arrive (ensure_pipe): pipeline 0 starts with room for one pass,
     // which also gives v4r_trace_rays its stack spill slab.
-    if (int rc = ensure_pipe(r, r->pipes[0], r->npix)) return rc;
+    if (int rc = ensure_pipe(r, r->pipes[0], r->npix, 1)) return rc;
     // v4r_render_noalloc: this device's scratch array, carved into one more pipeline that runs on the public stream
     if (int rc = scratch_of_device(r->device, &r->scratch_ptr)) return rc;
     r->noalloc.stream = r->stream;
@@ -1580,6 +1631,9 @@ int run_batch(v4r_renderer *r, Pipe &pipe, uint64_t seed, uint32_t first_pass, u
         order.full_groups = n_batch_passes >> lp;
     }
     PrimaryArgs primary{(uint32_t)seed, (uint32_t)(seed >> 32), first_pass, pass_stride, n_paths, band_pix, band_offset, order};
+    pipe.Q.npix = band_pix;
+    pipe.Q.flags_offset = n_batch_passes * r->S.n_prims;
+    if (r->S.packet_rule && n_batch_passes > pipe.count_passes) return set_error(V4R_E_INVALID, "internal: batch larger than the pipeline's ray counters");
     // segments 0 .. n_wavefront-1 run as one trace launch (or two) and one shading launch per class; one k_tail finishes the rest
     const uint32_t n_wavefront = r->tail_segment >= 1u && r->tail_segment < r->S.max_depth ? r->tail_segment : r->S.max_depth;
     // v4r_profile_*: a pair of HIP events on this pipeline's stream around a group of launches
@@ -1609,6 +1663,8 @@ int run_batch(v4r_renderer *r, Pipe &pipe, uint64_t seed, uint32_t first_pass, u
         v4r_renderer::EventPair *pair = nullptr;
         if (int rc = bracket_begin(V4R_PROFILE_TRACE, pair)) return rc;
         uint32_t launches = 1;
+        if (!tail && r->S.packet_rule && seg < V4R_PACKET_COUNTED_LEVELS)  // deeper levels reuse the counts of the last counted one
+            HIP_TRY(hipMemsetAsync(pipe.Q.shape_rays, 0, 2 * (size_t)n_batch_passes * r->S.n_prims * sizeof(uint32_t), pipe.stream));
         if (tail) launch_tail(r, pipe, seg);  // timed with the trace launches: nearly all of it is traversal
         else launches = launch_trace(r, pipe, seg, primary);
         if (int rc = bracket_end(pair, launches)) return rc;
@@ -1715,6 +1771,7 @@ int v4r_render_rows(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_
     const uint32_t band_pix = n_rows * r->S.width;
     // passes per batch for this band: the same number of path slots as a full-image batch
     uint32_t batch = (uint32_t)std::min<uint64_t>((uint64_t)r->batch_passes * r->npix / band_pix, 4096u);
+    batch = cap_counted_passes(r, batch);
     if (batch >= 16u) batch &= ~15u;
     batch = std::max(1u, batch);
     // A job of fewer batches than pipelines is cut into one piece per pipeline (multiples of 16 passes, the
@@ -1733,7 +1790,7 @@ int v4r_render_rows(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_
         uint32_t nb = std::min(batch, n_passes - done);
         Pipe &pipe = r->pipes[r->next_pipe];
         r->next_pipe = (r->next_pipe + 1) % n_pipes;
-        if (int rc = ensure_pipe(r, pipe, (size_t)nb * band_pix)) return rc;
+        if (int rc = ensure_pipe(r, pipe, (size_t)nb * band_pix, nb)) return rc;
         if (int rc = run_batch(r, pipe, seed, first_pass + done * pass_stride, pass_stride, nb, row0, n_rows)) return rc;
         done += nb;
     }
@@ -1761,6 +1818,7 @@ int v4r_render_noalloc(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint
     if (pass_stride == 0) pass_stride = 1;
     HIP_TRY(hipSetDevice(r->device));
     uint32_t batch = std::min<uint32_t>(pipe.Q.cap / r->npix, 4096u);
+    if (r->S.packet_rule) batch = std::min(batch, NOALLOC_COUNTED_PASSES);
     if (batch >= 16u) batch &= ~15u;
     // One pipeline on the public stream: batches run one after the other, ordered after whatever the handle queued
     // before (v4r_render ends by joining its pipelines into this stream) and before whatever it queues next.

@@ -62,7 +62,9 @@ enum {
     DIM_LENS_R = 2,
     DIM_LENS_THETA = 3,
     DIM_TIME = 4,
-    DIM_SCATTER = 8,  // 8..15: material / pdf sampling at the end of the segment
+    DIM_SCATTER = 8,       // 8..13: material / pdf sampling at the end of the segment
+    DIM_PACKET_SLOT = 14,  // packet-statistics rule of the light pdf: is the ray in its shape's last, partial packet
+    DIM_PACKET_ANY = 16,   // 16..31, + (light index & 15): does a packet mate hit that light
     DIM_MEDIUM = 32   // 32..63: constant-medium free-path draw, + (primitive index & 31)
 };
 

@@ -42,6 +42,7 @@ struct SceneDev {
     const uint32_t *media_direct;  // primitives (constant media) tested before the tree instead of inside it
     uint32_t n_media_direct;
     uint32_t n_top_nodes;        // the first n_top_nodes wide nodes are the top levels of the tree (breadth first): k_trace keeps them in LDS
+    uint32_t packet_rule;        // the light pdf follows the packet-statistics rule (lights_value): the scene has lights and neither light-pdf flag
     float bg[3], env[3];
     v4r_camera cam;
     uint32_t width, height, max_depth, antialias;
@@ -673,54 +674,6 @@ V4R_DEV V3 random_to_sphere(float radius, float distance_squared, float u_phi, f
     return v3(c * xy, s * xy, z);
 }
 
-// Samplable::value of one light primitive: sphere.rs:100-131, aa_rect.rs:151-180,
-// triangle.rs:103-132, wrapped by TransformHittable::value (transform.rs:103-116, no Jacobian).
-// Without V4R_FLAG_BOUNDED_LIGHT_PDF a rectangle / triangle yields the un-clipped plane density,
-// which is what a SIMD lane of the reference gets whenever any lane of its packet hits the light.
-V4R_DEV float light_value(const SceneDev &S, uint32_t prim_index, V3 origin, V3 dir) {
-    Prim pr = load_prim(S.prims, prim_index);
-    uint32_t xf = pr.xform();
-    if (xf != V4R_NO_XFORM) {
-        const float *inv = S.xforms + 24 * (size_t)xf + 12;
-        origin = mat_mul(inv, origin) + v3(inv[9], inv[10], inv[11]);
-        dir = normalize(mat_mul(inv, dir));
-    }
-    bool bounded = S.flags & V4R_FLAG_BOUNDED_LIGHT_PDF;
-    uint32_t kind = pr.type() & V4R_PRIM_TYPE_MASK;
-    if (kind == V4R_PRIM_SPHERE) {
-        float t;
-        if (!sphere_t(pr, origin, dir, EPSILON, V4R_INF, t)) return 0.0f;
-        float radius = pr.a.w;
-        float cos_theta_max = sqrtf(1.0f - radius * radius / norm2(v3(pr.a.x, pr.a.y, pr.a.z) - origin));
-        float solid_angle = TWO_PI * (1.0f - cos_theta_max);
-        return solid_angle > 0.0f ? 1.0f / solid_angle : V4R_INF;
-    }
-    if (kind == V4R_PRIM_TRIANGLE) {
-        float t, u, v, det;
-        bool hit = tri_t(pr, origin, dir, EPSILON, V4R_INF, t, u, v, det);
-        if (bounded && !hit) return 0.0f;
-        const float4 *tp = S.tri + 4 * (size_t)pr.aux();
-        float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
-        float w = 1.0f - u - v;
-        V3 normal = normalize(v3(q0.x, q0.y, q0.z) * w + v3(q0.w, q1.x, q1.y) * u + v3(q1.z, q1.w, q2.x) * v);
-        V3 e12 = v3(pr.a.w, pr.b.x, pr.b.y), e13 = v3(pr.b.z, pr.b.w, pr.c.x);
-        float area = norm(cross(e12, e13)) * 0.5f;
-        float cosine = fabsf(dot(dir, normal));
-        return cosine > 0.0f ? (t * t) / (cosine * area) : V4R_INF;
-    }
-    if (kind <= V4R_PRIM_ZX_RECT) {
-        float t;
-        bool hit = rect_t(pr, origin, dir, EPSILON, V4R_INF, t);
-        if (bounded && !hit) return 0.0f;
-        int ia, ib, ik;
-        rect_axes(pr.type(), ia, ib, ik);
-        float area = (pr.a.y - pr.a.x) * (pr.a.w - pr.a.z);
-        float cosine = fabsf(comp(dir, ik));
-        return cosine > 0.0f ? (t * t) / (cosine * area) : V4R_INF;
-    }
-    return 0.0f;
-}
-
 // Samplable::generate: sphere.rs:132-144, aa_rect.rs:182-185 (+ rect_random!, :54-76),
 // triangle.rs:134-146, wrapped by TransformHittable::generate (transform.rs:118-124).
 V4R_DEV V3 light_generate(const SceneDev &S, uint32_t prim_index, V3 origin, float u0, float u1) {
@@ -762,11 +715,126 @@ V4R_DEV V3 light_generate(const SceneDev &S, uint32_t prim_index, V3 origin, flo
     return dir;
 }
 
-// HittableGroup::value over the light list, hittables/group.rs:76-89
-V4R_DEV float lights_value(const SceneDev &S, V3 origin, V3 dir) {
-    float weight = 1.0f / (float)S.n_lights;
+// Samplable::value of one light primitive (sphere.rs:100-131, aa_rect.rs:151-180, triangle.rs:103-132, wrapped by
+// TransformHittable::value, transform.rs:103-116, no Jacobian), as its two ingredients for one lane of a SIMD packet:
+// does the direction hit the light (`hit`), and the density the lane is given when the hit record of its packet is not all-miss -- for rectangles and triangles
+// the un-clipped plane density (t may be negative); a sphere masks with its own hit (`per_lane`, sphere.rs:107-130).
+V4R_DEV float light_probe(const SceneDev &S, const Prim &pr, V3 origin, V3 dir, bool &hit, bool &per_lane) {
+    uint32_t xf = pr.xform();
+    if (xf != V4R_NO_XFORM) {
+        const float *inv = S.xforms + 24 * (size_t)xf + 12;
+        origin = mat_mul(inv, origin) + v3(inv[9], inv[10], inv[11]);
+        dir = normalize(mat_mul(inv, dir));
+    }
+    uint32_t kind = pr.type() & V4R_PRIM_TYPE_MASK;
+    per_lane = false;
+    hit = false;
+    if (kind == V4R_PRIM_SPHERE) {
+        per_lane = true;
+        float t;
+        hit = sphere_t(pr, origin, dir, EPSILON, V4R_INF, t);
+        if (!hit) return 0.0f;
+        float radius = pr.a.w;
+        float cos_theta_max = sqrtf(1.0f - radius * radius / norm2(v3(pr.a.x, pr.a.y, pr.a.z) - origin));
+        float solid_angle = TWO_PI * (1.0f - cos_theta_max);
+        return solid_angle > 0.0f ? 1.0f / solid_angle : V4R_INF;
+    }
+    if (kind == V4R_PRIM_TRIANGLE) {
+        float t, u, v, det;
+        hit = tri_t(pr, origin, dir, EPSILON, V4R_INF, t, u, v, det);
+        const float4 *tp = S.tri + 4 * (size_t)pr.aux();
+        float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+        float w = 1.0f - u - v;
+        V3 normal = normalize(v3(q0.x, q0.y, q0.z) * w + v3(q0.w, q1.x, q1.y) * u + v3(q1.z, q1.w, q2.x) * v);
+        V3 e12 = v3(pr.a.w, pr.b.x, pr.b.y), e13 = v3(pr.b.z, pr.b.w, pr.c.x);
+        float area = norm(cross(e12, e13)) * 0.5f;
+        float cosine = fabsf(dot(dir, normal));
+        return cosine > 0.0f ? (t * t) / (cosine * area) : V4R_INF;
+    }
+    if (kind <= V4R_PRIM_ZX_RECT) {
+        float t;
+        hit = rect_t(pr, origin, dir, EPSILON, V4R_INF, t);
+        int ia, ib, ik;
+        rect_axes(pr.type(), ia, ib, ik);
+        float area = (pr.a.y - pr.a.x) * (pr.a.w - pr.a.z);
+        float cosine = fabsf(comp(dir, ik));
+        return cosine > 0.0f ? (t * t) / (cosine * area) : V4R_INF;
+    }
+    per_lane = true;
+    return 0.0f;
+}
+
+// The share of a cosine-distributed direction from surface point p (normal n) that hits an untransformed rectangle or
+// triangle light, estimated from the light's centre, area and normal; 0 for transformed lights and other kinds.
+V4R_DEV float light_cosine_share(const Prim &pr, V3 p, V3 n) {
+    if (pr.xform() != V4R_NO_XFORM) return 0.0f;
+    V3 centre, ln;
+    float area;
+    uint32_t kind = pr.type() & V4R_PRIM_TYPE_MASK;
+    if (kind == V4R_PRIM_TRIANGLE) {
+        V3 e12 = v3(pr.a.w, pr.b.x, pr.b.y), e13 = v3(pr.b.z, pr.b.w, pr.c.x), c = cross(e12, e13);
+        centre = v3(pr.a.x, pr.a.y, pr.a.z) + (e12 + e13) * (1.0f / 3.0f);
+        float len = norm(c);
+        ln = c / len;
+        area = len * 0.5f;
+    } else if (kind >= V4R_PRIM_XY_RECT && kind <= V4R_PRIM_ZX_RECT) {
+        int ia, ib, ik;
+        rect_axes(pr.type(), ia, ib, ik);
+        float ca = 0.5f * (pr.a.x + pr.a.y), cb = 0.5f * (pr.a.z + pr.a.w), ck = pr.b.x;
+        centre = v3(ia == 0 ? ca : (ib == 0 ? cb : ck), ia == 1 ? ca : (ib == 1 ? cb : ck), ia == 2 ? ca : (ib == 2 ? cb : ck));
+        ln = v3(ik == 0 ? 1.0f : 0.0f, ik == 1 ? 1.0f : 0.0f, ik == 2 ? 1.0f : 0.0f);
+        area = (pr.a.y - pr.a.x) * (pr.a.w - pr.a.z);
+    } else {
+        return 0.0f;
+    }
+    V3 w = centre - p;
+    float d2 = norm2(w), d = sqrtf(d2);
+    float cos_l = fabsf(dot(w, ln)) / d, cos_p = dot(w, n) / d;
+    if (!(cos_p > 0.0f)) return 0.0f;
+    float h = area * cos_l * cos_p / (PI * d2);
+    return h < 1.0f ? h : 1.0f;
+}
+
+// HittableGroup::value over the light list (hittables/group.rs:76-89).  What a rectangle or triangle light gives a
+// direction that misses it depends on the scene's rule:
+//   V4R_FLAG_BOUNDED_LIGHT_PDF  0 (the textbook density);
+//   V4R_FLAG_PLANE_LIGHT_PDF    the un-clipped plane density, always;
+//   neither (S.packet_rule)     the packet-statistics rule: what the reference's 8-lane packets do to the pdf, in
+// expectation, without forming the packets.  There a lane whose direction misses such a light gets the plane density
+// when some lane of its packet hits the light and 0 when none does (aa_rect.rs:158-179, triangle.rs:110-131); a packet
+// holds rays of one pass and level that hit the same shape (renderer.rs:189-217).  `n` rays hit this ray's shape: they
+// are cut into packets of 8, the last holding n mod 8, and the ray sits in that one with probability (n mod 8) / n (one
+// draw; from V4R_PACKET_MANY_RAYS rays on every packet counts as full); each of the k - 1 mates samples the light the
+// packet drew (`li`, mixture.rs:27-32, group.rs:91-95) half of the time -- that direction hits it -- and a cosine
+// direction otherwise, which hits light L with probability h_L (light_cosine_share); so no mate hits L with
+// probability (1 - (0.5 [L == li] + 0.5 h_L))^(k-1), decided by one more draw per light.
+V4R_DEV float lights_value(const SceneDev &S, V3 origin, V3 normal, V3 dir, uint32_t li, uint32_t n, uint32_t key) {
+    const bool bounded = (S.flags & V4R_FLAG_BOUNDED_LIGHT_PDF) != 0u, stat = S.packet_rule != 0u;
+    uint32_t k = 8u;
+    if (n < 8u) {
+        k = n < 1u ? 1u : n;
+    } else if (n < V4R_PACKET_MANY_RAYS) {
+        uint32_t r = n % 8u;
+        if (r != 0u && draw(key, DIM_PACKET_SLOT) * (float)n < (float)r) k = r;
+    }
+    const float weight = 1.0f / (float)S.n_lights;
     float sum = 0.0f;
-    for (uint32_t i = 0; i < S.n_lights; ++i) sum += weight * light_value(S, S.lights[i], origin, dir);
+    for (uint32_t l = 0; l < S.n_lights; ++l) {
+        Prim pr = load_prim(S.prims, S.lights[l]);
+        bool hit, per_lane;
+        float density = light_probe(S, pr, origin, dir, hit, per_lane);
+        if (!per_lane && !hit) {
+            if (bounded) {
+                density = 0.0f;
+            } else if (stat) {
+                float q = 1.0f - (0.5f * (l == li ? 1.0f : 0.0f) + 0.5f * light_cosine_share(pr, origin, normal));
+                float p_none = 1.0f;
+                for (uint32_t m = 1u; m < k; ++m) p_none = p_none * q;
+                if (!(draw(key, DIM_PACKET_ANY + (l & 15u)) >= p_none)) density = 0.0f;
+            }
+        }
+        sum += weight * density;
+    }
     return sum;
 }
 

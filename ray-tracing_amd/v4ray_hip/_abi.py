@@ -14,6 +14,7 @@ V4R_LEAF_BIT = 0x80000000
 V4R_NO_XFORM = 0xFFFFFFFF
 V4R_FLAG_BOUNDED_LIGHT_PDF = 0x1
 V4R_FLAG_KEEP_HOST_BVH = 0x2
+V4R_FLAG_PLANE_LIGHT_PDF = 0x4
 
 V4R_PRIM_SPHERE, V4R_PRIM_XY_RECT, V4R_PRIM_YZ_RECT, V4R_PRIM_ZX_RECT, V4R_PRIM_TRIANGLE, V4R_PRIM_MEDIUM = range(6)
 V4R_PRIM_TYPE_MASK = 0xFF

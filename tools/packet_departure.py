@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--flags", type=int, default=0, help="scene flags for the mode-0 side (1 = bounded light pdf)")
+    ap.add_argument("--mode", type=int, default=0, help="the oracle mode compared with mode 2: 0 = scalar rule (flags pick the pdf), 3 = packet-statistics rule")
     ap.add_argument("--out", default="")
     ap.add_argument("--save-images", default="", help="npz of both mean images, box-filtered down 8x")
     args = ap.parse_args()
@@ -60,7 +61,7 @@ def main():
     marks = {m for m in (16, 64, 256, 1024, 2048, 4096, 8192) if m <= args.spp} | {args.spp}
     while done < args.spp:
         n = min(args.block, args.spp - done)
-        oracle.render(d0, n, first_pass=done, threads=args.threads, mode=0, accum=a0)
+        oracle.render(d0, n, first_pass=done, threads=args.threads, mode=args.mode, accum=a0)
         oracle.render(d2, n, first_pass=done, threads=args.threads, mode=2, accum=a2)
         done += n
         if done in marks:
@@ -76,9 +77,9 @@ def main():
             print(json.dumps(row), flush=True)
             if args.out:
                 with open(args.out, "w") as f:
-                    json.dump({"workload": args.workload, "width": w, "height": h, "mode0_flags": args.flags,
+                    json.dump({"workload": args.workload, "width": w, "height": h, "mode0_flags": args.flags, "compared_mode": args.mode,
                                "mesh_pixel_fraction": float(on_mesh.mean()),
-                               "what": "PSNR (sqrt-gamma display values, clipped to [0,1]) between oracle mode 0 (scalar rule) and mode 2 "
+                               "what": "PSNR (sqrt-gamma display values, clipped to [0,1]) between oracle mode `compared_mode` (keys say mode0; 0 = scalar rule, 3 = packet-statistics rule) and mode 2 "
                                        "(the reference's 8-lane packets), same passes, same random streams",
                                "rows": rows}, f, indent=1)
             if args.save_images:
