@@ -1288,9 +1288,30 @@ int v4o_render(const v4r_scene_desc *s, uint64_t seed, uint32_t first_pass, uint
     // work counts, keeps the per-path loop and the plane density: the paths are the same, only their weights differ).
     const bool packet_rule = s->n_lights != 0 && !(s->flags & (V4R_FLAG_BOUNDED_LIGHT_PDF | V4R_FLAG_PLANE_LIGHT_PDF));
     if (mode == 2 || mode == 3 || (packet_rule && pixel_stride == 1)) {  // whole passes, breadth first
-        const int rule = mode == 2 ? 2 : 3;
-        for (uint32_t k = 0; k < n_passes; ++k)
-            render_pass_packets(s, seed, first_pass + k * pass_stride, accum, n_threads, counters, rule, mode == 1 ? 1 : 0, &wide);
+        const int rule = mode == 2 ? 2 : 3, trace_mode = mode == 1 ? 1 : 0;
+        if (n_threads > 1 && n_passes > 1 && npix <= (1u << 18)) {
+            // small image: one pass per thread, each into its own buffer; a pass adds exactly one term per pixel, so adding
+            // the buffers in pass order gives the bits of the sequential loop
+            std::vector<std::vector<float>> buf((size_t)n_threads, std::vector<float>((size_t)npix * 3));
+            std::vector<std::vector<Counters>> own((size_t)n_threads, std::vector<Counters>(1));
+            for (uint32_t k0 = 0; k0 < n_passes; k0 += (uint32_t)n_threads) {
+                const uint32_t group = std::min<uint32_t>((uint32_t)n_threads, n_passes - k0);
+                std::vector<std::thread> threads;
+                auto one = [&](uint32_t t) {
+                    std::fill(buf[t].begin(), buf[t].end(), 0.0f);
+                    render_pass_packets(s, seed, first_pass + (k0 + t) * pass_stride, buf[t].data(), 1, own[t], rule, trace_mode, &wide);
+                };
+                for (uint32_t t = 1; t < group; ++t) threads.emplace_back(one, t);
+                one(0);
+                for (auto &t : threads) t.join();
+                for (uint32_t t = 0; t < group; ++t)
+                    for (size_t q = 0; q < (size_t)npix * 3; ++q) accum[q] += buf[t][q];
+            }
+            for (int t = 0; t < n_threads; ++t) counters[(size_t)t].add(own[(size_t)t][0]);
+        } else {
+            for (uint32_t k = 0; k < n_passes; ++k)
+                render_pass_packets(s, seed, first_pass + k * pass_stride, accum, n_threads, counters, rule, trace_mode, &wide);
+        }
         report();
         return V4R_OK;
     }

@@ -25,9 +25,29 @@ PRIMARY_SIZE = {"c1": (64, 64), "c2": (96, 54), "c3": (64, 64), "c4": (96, 54), 
 IMAGE_SIZE = {"c1": (96, 96), "c2": (128, 72), "c3": (96, 96), "c4": (128, 72), "c5": (128, 72)}
 IMAGE_SPP = 1024
 SEED = 0x5EED
+PACKET_SPP = 16384     # the reference's own 8-lane packets (oracle mode 2), for the independent-stream convergence gate
+PACKET_SEED = 0xA11CE
+
+
+def packets_only():
+    """Adds (or refreshes) the reference-packet images in the existing golden.npz, one scene at a time."""
+    path = os.path.join(HERE, "golden.npz")
+    for name, (w, h) in IMAGE_SIZE.items():
+        out = dict(np.load(path))
+        key = f"{name}_packets_{PACKET_SPP}spp"
+        if key in out and "--force" not in sys.argv:
+            continue
+        s = scenes.load(name, w, h)
+        d = s.flatten(s.renderer_param, s.camera_param)
+        ref, _ = oracle.render(d, PACKET_SPP, seed=PACKET_SEED, mode=2)
+        out[key] = (ref / PACKET_SPP).astype(np.float32)
+        np.savez_compressed(path, **out)
+        print(name, "reference-packet image mean", ref.mean() / PACKET_SPP, flush=True)
 
 
 def main():
+    if "--packets-only" in sys.argv:
+        return packets_only()
     out = {}
     for name, (w, h) in PRIMARY_SIZE.items():
         s = scenes.load(name, w, h)
@@ -44,6 +64,9 @@ def main():
         img16, _ = oracle.render(d, 16, seed=SEED)
         out[f"{name}_image_16spp_sum"] = img16
         print(name, "image mean", img.mean() / IMAGE_SPP, stats)
+        ref, _ = oracle.render(d, PACKET_SPP, seed=PACKET_SEED, mode=2)
+        out[f"{name}_packets_{PACKET_SPP}spp"] = (ref / PACKET_SPP).astype(np.float32)
+        print(name, "reference-packet image mean", ref.mean() / PACKET_SPP, flush=True)
     earth = load_image(os.path.join(scenes.ASSETS, "earthmap.jpg"))
     out["earthmap_sha256"] = np.frombuffer(hashlib.sha256(earth.tobytes()).digest(), dtype=np.uint8)
     out["earthmap_row_means"] = earth.reshape(512, -1).mean(axis=1).astype(np.float32)
