@@ -44,9 +44,6 @@ static __device__ __align__(256) unsigned char scratch[V4R_NOALLOC_SCRATCH_BYTES
 namespace {
 
 constexpr int BLOCK = 256;
-#ifndef V4R_COUNT_VARIANT
-#define V4R_COUNT_VARIANT 4
-#endif
 #ifndef V4R_TRACE_RAYS_PER_THREAD
 #define V4R_TRACE_RAYS_PER_THREAD 4
 #endif
@@ -279,7 +276,8 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
     // packet-statistics rule of the light pdf: the first levels count the rays that end on each Lambertian shape
     const bool count_shape_rays = S.packet_rule != 0u && seg < V4R_PACKET_COUNTED_LEVELS;
     TraceCounters cnt;
-    uint32_t n_traced = 0;
+    uint32_t n_traced = 0, n_lights = 0;
+    constexpr uint32_t DEST_NONE = 0xFFu;
     bool started = false;
     // A short queue is spread over as many workgroups as possible: a thread then traces fewer rays per
     // chunk (down to one), so the launch lasts about one ray's traversal instead of RAYS_PER_THREAD.
@@ -341,10 +339,11 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
                     return segment_key(k0, k1, seg);
                 };
                 bool gave_up = traverse<COUNT, MEDIA>(S, o, d, active, st, best, cnt, key, second ? 0u : give_up_lanes, second);
-                uint32_t w = 0xFFFFFFFFu;
+                // what becomes of the ray: the queue it goes to (a shading class, or CLS_COUNT = given up), or none (its path ended)
+                uint32_t dest = DEST_NONE;
                 if (active && gave_up) {
                     Q.hitd[i] = make_float4(best.t, __uint_as_float(best.prim), best.u, best.v);
-                    w = ((uint32_t)CLS_COUNT << 16) | atomicAdd(&s_cnt[CLS_COUNT], 1u);
+                    dest = (uint32_t)CLS_COUNT;
                 } else if (active) {
                     if (COUNT) n_traced++;
                     if (best.prim != NO_PRIM) {
@@ -360,22 +359,37 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
                             n_rays += (size_t)pass * S.n_prims + best.prim;
                             full = n_rays[Q.flags_offset];
                         }
-                        uint32_t cls = S.prim_info[best.prim] >> 24;
-                        Q.hitd[i] = make_float4(best.t, __uint_as_float(best.prim), best.u, best.v);
-                        w = (cls << 16) | atomicAdd(&s_cnt[cls], 1u);
-#if V4R_COUNT_VARIANT == 4
-                        if (count_shape_rays && (cls == (uint32_t)CLS_LAMBERT || cls == (uint32_t)CLS_LAMBERT_NOISE) && full == 0u &&
-                            atomicAdd(n_rays, 1u) + 1u >= V4R_PACKET_MANY_RAYS)
-                            n_rays[Q.flags_offset] = 1u;
-#endif
-                        if (PRIMARY) {
-                            PathState p;
-                            p.o = o;
-                            p.d = d;
-                            p.thr = v3(1, 1, 1);
-                            p.slot = pass_in_batch * npix + pixel;
-                            path_key(A.seed_lo, A.seed_hi, A.first_pass + pass_in_batch * A.pass_stride, pixel + A.pixel_offset, p.k0, p.k1);
-                            store_ray(rq, i, p);
+                        const uint32_t info = S.prim_info[best.prim], cls = info >> 24;
+                        if (info & PRIM_INFO_PLAIN_LIGHT) {
+                            // DiffuseLight (material/diffuse_light.rs:19-22) of one colour on an untransformed rectangle: the
+                            // path ends here with throughput x emitted; nothing is queued for a shading launch.  The face test
+                            // is HitRecord::face_normal (hittable/mod.rs:146-154) against the rectangle's axis normal.
+                            const uint4 colour = S.prim_shade[2 * (size_t)best.prim];
+                            const float along = comp(d, (int)((info >> PRIM_INFO_AXIS_SHIFT) & 3u));
+                            const bool front = ((info & PRIM_INFO_POSITIVE) ? along : -along) < 0.0f;
+                            V3 e = front ? v3(__uint_as_float(colour.y), __uint_as_float(colour.z), __uint_as_float(colour.w)) : v3(0, 0, 0);
+                            if (PRIMARY) {
+                                Q.rad[pass_in_batch * npix + pixel] = make_float4(1.0f * e.x, 1.0f * e.y, 1.0f * e.z, 0.0f);
+                            } else {
+                                float4 bb = rq[1][i], c = rq[2][i];
+                                Q.rad[__float_as_uint(bb.z)] = make_float4(bb.w * e.x, c.x * e.y, c.y * e.z, 0.0f);
+                            }
+                            if (COUNT) n_lights++;
+                        } else {
+                            Q.hitd[i] = make_float4(best.t, __uint_as_float(best.prim), best.u, best.v);
+                            dest = cls;
+                            if (count_shape_rays && (cls == (uint32_t)CLS_LAMBERT || cls == (uint32_t)CLS_LAMBERT_NOISE) && full == 0u &&
+                                atomicAdd(n_rays, 1u) + 1u >= V4R_PACKET_MANY_RAYS)
+                                n_rays[Q.flags_offset] = 1u;
+                            if (PRIMARY) {
+                                PathState p;
+                                p.o = o;
+                                p.d = d;
+                                p.thr = v3(1, 1, 1);
+                                p.slot = pass_in_batch * npix + pixel;
+                                path_key(A.seed_lo, A.seed_hi, A.first_pass + pass_in_batch * A.pass_stride, pixel + A.pixel_offset, p.k0, p.k1);
+                                store_ray(rq, i, p);
+                            }
                         }
                     } else if (PRIMARY) {  // renderer.rs:184: a miss takes the background colour
                         Q.rad[pass_in_batch * npix + pixel] = make_float4(S.bg[0], S.bg[1], S.bg[2], 0.0f);
@@ -383,6 +397,20 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
                         float4 bb = rq[1][i], c = rq[2][i];
                         Q.rad[__float_as_uint(bb.z)] = make_float4(bb.w * S.bg[0], c.x * S.bg[1], c.y * S.bg[2], 0.0f);
                     }
+                }
+                // Rank of the ray among the chunk's rays with the same destination: the lanes of the wave that share a
+                // destination are found by ballot, one of them reserves their ranks with a single LDS atomic, and each
+                // takes the rank of its position among them.
+                uint32_t w = 0xFFFFFFFFu;
+                for (unsigned long long todo = __ballot(dest != DEST_NONE); todo != 0ull;) {
+                    const int leader = __ffsll((long long)todo) - 1;
+                    const uint32_t which = (uint32_t)__shfl((int)dest, leader, 64);
+                    const unsigned long long same = __ballot(dest == which);
+                    uint32_t first = 0u;
+                    if ((int)lane_id() == leader) first = atomicAdd(&s_cnt[which], (uint32_t)__popcll(same));
+                    first = (uint32_t)__shfl((int)first, leader, 64);
+                    if (dest == which) w = (which << 16) | (first + (uint32_t)__popcll(same & ((1ull << lane_id()) - 1ull)));
+                    todo &= ~same;
                 }
                 s_where[j * BLOCK + threadIdx.x] = w;
             }
@@ -407,11 +435,12 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
         __syncthreads();
     }
     if (COUNT) {
-        unsigned long long s = wave_sum(n_traced), n = wave_sum(cnt.nodes), q = wave_sum(cnt.prims);
+        unsigned long long s = wave_sum(n_traced), n = wave_sum(cnt.nodes), q = wave_sum(cnt.prims), l = wave_sum(n_lights);
         if (lane_id() == 0) {
             atomicAdd(&Q.stats[0], s);
             atomicAdd(&Q.stats[1], n);
             atomicAdd(&Q.stats[2], q);
+            atomicAdd(&Q.stats[4], l);  // lights shaded here count as shaded hits
             atomicAdd(&Q.stats[6], (unsigned long long)cnt.wave_steps);
             atomicAdd(&Q.stats[7], (unsigned long long)cnt.wave_leaves);
         }
@@ -899,7 +928,7 @@ int validate(const v4r_scene_desc *d, uint32_t &depth_out) {
     if (int rc = need(d->images, d->n_images, "images")) return rc;
     if (int rc = need(d->perlin, d->n_perlin, "perlin")) return rc;
     if (int rc = need(d->lights, d->n_lights, "lights")) return rc;
-    if (d->n_materials > 0xFFFFFFu) return set_error(V4R_E_LIMIT, "too many materials");
+    if (d->n_materials > 0xFFFFFu) return set_error(V4R_E_LIMIT, "too many materials");
 
     // BVH: n-1 interior nodes for n >= 2 primitives, every primitive reachable exactly once.
     if (d->n_prims <= 1) {
@@ -1407,11 +1436,22 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     }
     if (int rc = r->upload(&S.prims, (const float4 *)d->prims, (size_t)d->n_prims * 3)) return rc;
     std::vector<uint32_t> info(d->n_prims);
+    bool plain_lights = true;
+    if (const char *env = std::getenv("V4R_PLAIN_LIGHTS")) plain_lights = std::atoi(env) != 0;
     for (uint32_t i = 0; i < d->n_prims; ++i) {
         const v4r_material &mat = d->materials[d->prim_material[i]];
         uint32_t cls = class_of(d, mat);
         info[i] = d->prim_material[i] | (cls << 24);
-        r->has_class[cls] = true;
+        // a one-colour light on an untransformed rectangle ends its paths inside k_trace (no queue, no shading launch)
+        const v4r_prim &pr = d->prims[i];
+        const uint32_t kind = pr.type & V4R_PRIM_TYPE_MASK;
+        if (plain_lights && cls == CLS_LIGHT && d->textures[mat.tex].kind == V4R_TEX_SOLID && pr.xform == V4R_NO_XFORM &&
+            (kind == V4R_PRIM_XY_RECT || kind == V4R_PRIM_YZ_RECT || kind == V4R_PRIM_ZX_RECT)) {
+            const uint32_t axis = kind == V4R_PRIM_XY_RECT ? 2u : (kind == V4R_PRIM_YZ_RECT ? 0u : 1u);
+            info[i] |= PRIM_INFO_PLAIN_LIGHT | (axis << PRIM_INFO_AXIS_SHIFT) | ((pr.type & V4R_PRIM_POSITIVE) ? PRIM_INFO_POSITIVE : 0u);
+        } else {
+            r->has_class[cls] = true;
+        }
         bool textured = mat.kind == V4R_MAT_LAMBERTIAN || mat.kind == V4R_MAT_DIFFUSE_LIGHT || mat.kind == V4R_MAT_ISOTROPIC;
         if (textured && has_noise(d, mat.tex)) r->class_noise[cls] = true;
     }

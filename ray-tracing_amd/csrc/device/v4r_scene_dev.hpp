@@ -20,13 +20,17 @@ enum {
 };
 
 constexpr uint32_t NO_PRIM = 0xFFFFFFFFu;
+// prim_info word: material index (20 bits) | flags | shading class << 24
+constexpr uint32_t PRIM_INFO_PLAIN_LIGHT = 1u << 23;  // one-colour DiffuseLight on an untransformed rectangle: k_trace ends the path itself
+constexpr uint32_t PRIM_INFO_POSITIVE = 1u << 22;     // ... whose outward normal points along +axis
+constexpr uint32_t PRIM_INFO_AXIS_SHIFT = 20;         // ... axis of that normal (2 bits)
 constexpr size_t MAX_DIRECT_MEDIA = 4;  // each costs every ray about a sixth of an average traversal
 
 struct SceneDev {
     const float4 *nodes4;        // 8 x float4 per 4-wide node (wide_step)
     const float4 *prims;         // 3 x float4 per primitive (v4r_prim)
     const uint4 *prim_shade;     // 2 x uint4 per primitive: its material's root texture record (textured materials) or material record
-    const uint32_t *prim_info;   // material index | shading class << 24
+    const uint32_t *prim_info;   // material index | PRIM_INFO_* | shading class << 24
     const float *xforms;         // 24 floats per transform (v4r_xform)
     const float4 *tri;           // 4 x float4 per triangle (v4r_tri_shading)
     const uint4 *media;          // v4r_medium
