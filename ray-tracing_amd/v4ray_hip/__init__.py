@@ -13,6 +13,8 @@ import asyncio
 import threading
 import ctypes as C
 import os
+import sys
+import types
 from typing import Optional, Sequence, Tuple
 
 import numpy as np
@@ -21,8 +23,9 @@ from . import _abi
 from ._abi import V4RayError, check_dev, check_host, device_lib, host_lib
 
 Vec3 = Tuple[float, float, float]
-__all__ = ["Scene", "RendererParam", "PerspectiveCameraParam", "Renderer", "AABB", "shape", "material", "texture",
-           "V4RayError"]
+__all__ = ["Scene", "RendererParam", "PerspectiveCameraParam", "Renderer", "AABB", "Ray", "HitRecord", "shape", "material",
+           "texture", "install_as", "V4RayError"]
+LANES = 8  # the reference's Python surface exchanges rays and hits in packets of f32x8 (src/py.rs:22)
 
 
 def _f3(v: Sequence[float]):
@@ -48,6 +51,66 @@ class AABB:
 
     def __repr__(self):
         return f"AABB(min={self._min}, max={self._max})"
+
+
+def _lanes(a, rows, what, dtype=np.float32):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    want = (rows, LANES) if rows else (LANES,)
+    if a.shape != want:
+        raise ValueError(f"{what}: expected an array of shape {want}, got {a.shape}")
+    return a
+
+
+class Ray:
+    """A packet of LANES rays (src/ray.rs:193-275): `origin` and `direction` are (3, LANES) float32 arrays, `time`
+    (LANES,) float32 and `mask` (LANES,) bool.  The reference only ever creates these on its Rust side; here they can
+    also be built from arrays (directions are normalised, as `From<&PyRay> for Ray` does, ray.rs:237-241)."""
+
+    def __init__(self, origin, direction, time=None, mask=None):
+        self._origin = _lanes(origin, 3, "origin")
+        d = _lanes(direction, 3, "direction")
+        with np.errstate(invalid="ignore", divide="ignore"):
+            self._direction = (d / np.sqrt((d * d).sum(axis=0, dtype=np.float32))).astype(np.float32)
+        self._time = _lanes(np.zeros(LANES, np.float32) if time is None else time, 0, "time")
+        self._mask = _lanes(np.ones(LANES, bool) if mask is None else mask, 0, "mask", bool)
+
+    @property
+    def origin(self) -> np.ndarray:
+        return self._origin.copy()
+
+    @property
+    def direction(self) -> np.ndarray:
+        return self._direction.copy()
+
+    @property
+    def time(self) -> np.ndarray:
+        return self._time.copy()
+
+    @property
+    def mask(self) -> np.ndarray:
+        return self._mask.copy()
+
+    def at(self, t) -> np.ndarray:
+        """Points origin + t * direction, (3, LANES) (ray.rs:146-150)."""
+        return (self._origin + self._direction * np.asarray(t, np.float32)).astype(np.float32)
+
+
+class HitRecord:
+    """The hits of a ray packet (src/hittable/mod.rs:18-31, src/hittable/py.rs:63-72): p and normal (3, LANES), t (LANES,),
+    uv (2, LANES), front_face and mask (LANES,) bool; lanes with mask False hold zeros (HitRecord::default).  The reference's
+    class is opaque to Python; the fields are readable here."""
+
+    def __init__(self, p=None, normal=None, t=None, uv=None, front_face=None, mask=None):
+        z = lambda rows: np.zeros((rows, LANES) if rows else (LANES,), np.float32)
+        self.p = z(3) if p is None else _lanes(p, 3, "p")
+        self.normal = z(3) if normal is None else _lanes(normal, 3, "normal")
+        self.t = z(0) if t is None else _lanes(t, 0, "t")
+        self.uv = z(2) if uv is None else _lanes(uv, 2, "uv")
+        self.front_face = np.zeros(LANES, bool) if front_face is None else _lanes(front_face, 0, "front_face", bool)
+        self.mask = np.zeros(LANES, bool) if mask is None else _lanes(mask, 0, "mask", bool)
+
+    def __repr__(self):
+        return f"HitRecord(t={self.t.tolist()}, mask={self.mask.tolist()})"
 
 
 class PerspectiveCameraParam:
@@ -143,12 +206,24 @@ class _Shape:
         return h
 
 
-class _Namespace:
-    pass
+def _submodule(name: str) -> types.ModuleType:
+    """A real, importable submodule (the reference adds `shape`, `material` and `texture` with add_submodule, src/py.rs:74-84)."""
+    m = types.ModuleType(f"{__name__}.{name}")
+    sys.modules[m.__name__] = m
+    return m
+
+
+def install_as(name: str = "v4ray") -> None:
+    """Make `import <name>`, `import <name>.shape`, `from <name>.material import Metal` ... resolve to this package: the
+    reference's front end (v4ray_frontend/*.py, main.py) imports the renderer as `v4ray`."""
+    me = sys.modules[__name__]
+    sys.modules[name] = me
+    for sub in ("shape", "material", "texture"):
+        sys.modules[f"{name}.{sub}"] = getattr(me, sub)
 
 
 # ---- v4ray.texture ---------------------------------------------------------------------------------
-texture = _Namespace()
+texture = _submodule("texture")
 
 
 class SolidColor(_Texture):
@@ -201,7 +276,7 @@ class Noise(_Texture):
 texture.SolidColor, texture.Checker, texture.Image, texture.Noise = SolidColor, Checker, ImageTexture, Noise
 
 # ---- v4ray.material --------------------------------------------------------------------------------
-material = _Namespace()
+material = _submodule("material")
 
 
 class Lambertian(_Material):
@@ -258,7 +333,7 @@ material.Lambertian, material.Metal, material.Dielectric = Lambertian, Metal, Di
 material.DiffuseLight, material.Isotropic = DiffuseLight, Isotropic
 
 # ---- v4ray.shape -----------------------------------------------------------------------------------
-shape = _Namespace()
+shape = _submodule("shape")
 
 
 class Sphere(_Shape):
@@ -278,6 +353,40 @@ class Sphere(_Shape):
     def bounding_box(self, time0: float = 0.0, time1: float = 0.0) -> AABB:
         c, r = np.float32(self._center), np.float32(self._radius)
         return AABB(tuple(float(x) for x in (c - r)), tuple(float(x) for x in (c + r)))
+
+    def hit(self, ray: Ray, t_min, t_max) -> HitRecord:
+        """Sphere::hit on a packet (src/hittable/sphere.rs:60-92), in f32 like the reference: the nearer root inside
+        [t_min, t_max] if there is one, else the farther; outward normal flipped against the ray; sphere_uv."""
+        f = np.float32
+        t_min, t_max = _lanes(t_min, 0, "t_min"), _lanes(t_max, 0, "t_max")
+        o, d = ray._origin, ray._direction
+        centre = f(self._center).reshape(3, 1)
+        with np.errstate(all="ignore"):
+            oc = o - centre
+            half_b = (oc * d).sum(axis=0, dtype=f)
+            c = (oc * oc).sum(axis=0, dtype=f) - f(self._radius) * f(self._radius)
+            disc = half_b * half_b - c
+            mask = ray._mask & ~(disc < 0)
+            if not mask.any():
+                return HitRecord()
+            sqrt_d = np.sqrt(disc)
+            root1, root2 = -half_b - sqrt_d, -half_b + sqrt_d
+            mask1 = mask & (root1 >= t_min) & (root1 <= t_max)
+            mask2 = mask & (root2 >= t_min) & (root2 <= t_max)
+            mask = mask1 | mask2
+            if not mask.any():
+                return HitRecord()
+            t = np.where(mask1, root1, root2).astype(f)
+            p = (o + d * t).astype(f)
+            outward = p - centre
+            outward = (outward / np.sqrt((outward * outward).sum(axis=0, dtype=f))).astype(f)
+            front = (d * outward).sum(axis=0, dtype=f) < 0
+            normal = np.where(front, outward, -outward).astype(f)
+            theta = np.arccos(-outward[1])
+            phi = np.arctan2(-outward[2], outward[0]) + f(np.pi)
+            uv = np.stack([phi / f(2 * np.pi), theta * f(1 / np.pi)]).astype(f)
+        keep = lambda a: np.where(mask, a, 0).astype(a.dtype)   # lanes that miss carry nothing
+        return HitRecord(keep(p), keep(normal), keep(t), keep(uv), front & mask, mask)
 
     def _make(self):
         return host_lib().v4rh_shape_sphere(_f3(self._center), self._radius)

@@ -1,0 +1,143 @@
+"""The Python package as a drop-in for the reference's `v4ray` extension module (src/py.rs:62-86, v4ray/*.pyi): the
+reference's own front-end package (v4ray_frontend/, imported from /root/reference where it lies -- nothing of it is
+copied here) must import against it and build one object of every type it registers.  Runs only where the reference
+tree is present (the build container); the GPU box has no /root/reference."""
+import importlib
+import os
+import sys
+import uuid
+
+import numpy as np
+import pytest
+
+import v4ray_hip
+
+REFERENCE = "/root/reference"
+needs_reference = pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "v4ray_frontend")), reason="the reference tree is not present")
+
+
+def test_module_surface_matches_the_stubs():
+    """Names the stubs declare (v4ray/__init__.pyi, shape.pyi, material.pyi, texture.pyi), importable submodules included."""
+    v4ray_hip.install_as("v4ray")
+    v4ray = importlib.import_module("v4ray")
+    for name in ("Scene", "AABB", "Ray", "HitRecord", "PerspectiveCameraParam", "RendererParam", "Renderer"):
+        assert hasattr(v4ray, name), name
+    from v4ray.shape import Sphere
+    from v4ray.material import Dielectric, Lambertian, Metal
+    from v4ray.texture import Checker, SolidColor
+    assert importlib.import_module("v4ray.shape").Sphere is Sphere is v4ray_hip.Sphere
+    assert importlib.import_module("v4ray_hip.material").Metal is Metal
+    s = Sphere((1.0, 2.0, 3.0), 0.5)
+    assert s.center == (1.0, 2.0, 3.0) and s.radius == 0.5
+    box = s.bounding_box()
+    assert box.min == (0.5, 1.5, 2.5) and box.max == (1.5, 2.5, 3.5)
+    assert s.bounding_box(0.0, 1.0).max == box.max       # the two shutter times the Rust method takes (sphere.rs:162-165)
+    Lambertian(Checker(SolidColor((1, 0, 0)), SolidColor((0, 1, 0)), 2.0)), Metal((0.5, 0.5, 0.5), 0.1), Dielectric(1.5)
+    assert asyncio_iscoroutinefunction(v4ray.Renderer.render)
+
+
+def asyncio_iscoroutinefunction(f):
+    import asyncio
+    return asyncio.iscoroutinefunction(f)
+
+
+def test_sphere_hit_on_a_ray_packet():
+    """shape.Sphere.hit(ray, t_min, t_max) -> HitRecord (v4ray/shape.pyi, sphere.rs:60-92,166-179) on eight rays: head-on,
+    from inside, grazing miss, masked-off lane, hit behind t_max, hit before t_min."""
+    from v4ray_hip import HitRecord, Ray, Sphere
+    s = Sphere((0.0, 0.0, 5.0), 1.0)
+    o = np.zeros((3, 8), np.float32)
+    d = np.zeros((3, 8), np.float32)
+    d[2] = 1.0
+    o[:, 1] = (0, 0, 5)            # from the centre: the far root
+    o[0, 2] = 1.5                  # passes beside the sphere
+    o[0, 4] = 0.6                  # off-axis hit
+    d[:, 5] = (0, 0, -1)           # looks away
+    mask = np.ones(8, bool)
+    mask[3] = False
+    t_min = np.full(8, 1e-3, np.float32)
+    t_max = np.full(8, np.inf, np.float32)
+    t_max[6] = 3.0                 # both roots beyond t_max
+    t_min[7] = 4.5                 # the near root before t_min: the far one counts
+    h = s.hit(Ray(o, d * 3.0, mask=mask), t_min, t_max)   # directions are normalised on the way in
+    assert isinstance(h, HitRecord)
+    assert h.mask.tolist() == [True, True, False, False, True, False, False, True]
+    assert np.allclose(h.t[[0, 1, 7]], [4.0, 1.0, 6.0])
+    assert np.allclose(h.t[4], 5.0 - np.sqrt(1 - 0.36), rtol=1e-6)
+    assert h.front_face.tolist() == [True, False, False, False, True, False, False, False]
+    assert np.allclose(h.normal[:, 0], (0, 0, -1)) and np.allclose(h.normal[:, 1], (0, 0, -1)) and np.allclose(h.normal[:, 7], (0, 0, -1))
+    assert np.allclose(h.p[:, 4], (0.6, 0, 4.2), atol=1e-6)
+    # sphere_uv (sphere.rs:38-45) of the outward normal (0, 0, -1): theta = acos(0), phi = atan2(1, 0) + pi
+    assert np.allclose(h.uv[:, 0], (0.75, 0.5), atol=1e-6)
+    assert (h.t[~h.mask] == 0).all() and (h.p[:, ~h.mask] == 0).all()
+    none = Sphere((0.0, 50.0, 0.0), 1.0).hit(Ray(o, d), t_min, t_max)   # no ray meets it: HitRecord::default
+    assert not none.mask.any() and not none.t.any()
+    with pytest.raises(ValueError):
+        s.hit(Ray(o, d), np.zeros(4, np.float32), t_max)
+    r = Ray(o, d * 2.0)
+    assert r.origin.shape == (3, 8) and r.direction.shape == (3, 8) and r.time.shape == (8,) and r.mask.dtype == bool
+    assert np.allclose(np.linalg.norm(r.direction, axis=0), 1.0)
+
+
+def test_sphere_hit_agrees_with_the_oracle():
+    """The packet method against the oracle's restatement of Sphere::hit, ray by ray."""
+    import oracle
+    from v4ray_hip import Lambertian, PerspectiveCameraParam, Ray, RendererParam, Scene, SolidColor, Sphere
+    centre, radius = (0.3, -0.2, 4.0), 1.3
+    scene = Scene((0, 0, 0))
+    scene.add(Sphere(centre, radius), Lambertian(SolidColor((0.5, 0.5, 0.5))))
+    desc = scene.flatten(RendererParam(8, 8), PerspectiveCameraParam((0, 0, 0), (0, 0, 1), 40.0))
+    rng = np.random.default_rng(3)
+    s = Sphere(centre, radius)
+    for _ in range(16):
+        o = rng.uniform(-1, 1, size=(3, 8)).astype(np.float32)
+        d = (np.float32([[0], [0], [1]]) + rng.normal(size=(3, 8)) * 0.35).astype(np.float32)
+        ray = Ray(o, d)
+        h = s.hit(ray, np.full(8, 1e-3, np.float32), np.full(8, np.inf, np.float32))
+        for k in range(8):
+            ref = oracle.hit(desc, 0, ray.origin[:, k], ray.direction[:, k])
+            assert bool(h.mask[k]) == ref["mask"]
+            if ref["mask"]:
+                assert np.allclose(h.t[k], ref["t"], rtol=2e-6) and np.allclose(h.p[:, k], ref["p"], atol=2e-6)
+                assert np.allclose(h.normal[:, k], ref["normal"], atol=2e-6) and bool(h.front_face[k]) == ref["front_face"]
+                assert np.allclose(h.uv[:, k], (ref["u"], ref["v"]), atol=2e-6)
+
+
+@needs_reference
+def test_reference_front_end_builds_its_objects_against_this_package():
+    """`import v4ray_frontend` evaluates v4ray.Ray / v4ray.HitRecord / v4ray.AABB at import (v4ray_frontend/shape.py:11-13)
+    and every registered type's apply() constructs through v4ray.shape / v4ray.material / v4ray.texture / v4ray
+    (shape.py:74, material.py:72-159, texture.py:65,104, camera.py:81-103)."""
+    v4ray_hip.install_as("v4ray")
+    sys.path.insert(0, REFERENCE)
+    try:
+        for m in [k for k in sys.modules if k == "v4ray_frontend" or k.startswith("v4ray_frontend.")]:
+            del sys.modules[m]
+        fe = importlib.import_module("v4ray_frontend")
+    finally:
+        sys.path.remove(REFERENCE)
+    assert [t.kind() for t in fe.shapes] == ["sphere"]
+    red, green = uuid.uuid4(), uuid.uuid4()
+    textures = {red: fe.SolidColor.apply([(255, 0, 0)], {}), green: fe.SolidColor.apply([(0, 255, 0)], {})}
+    check = uuid.uuid4()
+    textures[check] = fe.Checker.apply([red, green, 2.0], textures)
+    assert isinstance(textures[red], v4ray_hip.SolidColor) and isinstance(textures[check], v4ray_hip.Checker)
+    materials = []
+    for mt in fe.materials:
+        data = {"lambertian": [check], "metal": [(200, 200, 255), 0.1], "dielectric": [1.5]}[mt.kind()]
+        materials.append(mt.apply(data, textures))
+        mt.apply_preview(data, textures)
+    assert [type(m) for m in materials] == [v4ray_hip.Lambertian, v4ray_hip.Metal, v4ray_hip.Dielectric]
+    shapes = fe.Sphere.apply([0.0, 1.0, 0.0, 1.0])
+    assert len(shapes) == 1 and shapes[0].radius == 1.0
+    cam_data = [p.default if getattr(p, "default", None) is not None else 0.0 for p in fe.PerspectiveCamera.properties()]
+    assert fe.PerspectiveCamera.validate(cam_data)
+    camera = fe.PerspectiveCamera.apply(cam_data)
+    fe.PerspectiveCamera.apply_preview(cam_data)
+    assert isinstance(camera, v4ray_hip.PerspectiveCameraParam)
+    # what main.py's State.generate does with them (main.py:1985): a scene the host library flattens for the device
+    scene = v4ray_hip.Scene((0.7, 0.8, 1.0), (0.0, 0.0, 0.0))
+    for m in materials:
+        scene.add(shapes[0], m)
+    desc = scene.flatten(v4ray_hip.RendererParam(64, 48), camera)
+    assert desc.contents.n_prims == 3 and desc.contents.width == 64
