@@ -2,7 +2,10 @@
 // The reference decodes image textures with the `image` crate (src/json.rs:349-354); that
 // decoder is not in the reference tree, so exact texel parity with it is unpinned.  This decoder
 // uses the classic 13-bit fixed-point Loeffler/Ligtenberg/Moschytz inverse DCT and the JFIF
-// YCbCr conversion; chroma planes are upsampled by replication.
+// YCbCr conversion; chroma planes are upsampled by replication (the `image` crate interpolates subsampled chroma, so
+// texels of a chroma-subsampled file may differ from the reference's by a few levels along colour edges).  Every index
+// and bit count taken from the file is checked before use: a malformed file is an exception, never an out-of-bounds access.
+#include <algorithm>
 #include <cstring>
 #include <fstream>
 #include <sstream>
@@ -106,22 +109,24 @@ const uint8_t ZIGZAG[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 
                             41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
                             30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
-inline int fx(double x) { return (int)(x * 4096 + 0.5); }
-inline uint8_t clamp8(int x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
+// 64-bit intermediates: coefficients of a crafted file cannot overflow them
+typedef long long wide;
+inline wide fx(double x) { return (wide)(x * 4096 + 0.5); }
+inline uint8_t clamp8(wide x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
 
 struct Idct1D {
-    int x0, x1, x2, x3, t0, t1, t2, t3;
-    Idct1D(int s0, int s1, int s2, int s3, int s4, int s5, int s6, int s7) {
-        int p1, p2, p3, p4, p5;
+    wide x0, x1, x2, x3, t0, t1, t2, t3;
+    Idct1D(wide s0, wide s1, wide s2, wide s3, wide s4, wide s5, wide s6, wide s7) {
+        wide p1, p2, p3, p4, p5;
         p2 = s2;
         p3 = s6;
         p1 = (p2 + p3) * fx(0.5411961);
-        int e2 = p1 + p3 * fx(-1.847759065);
-        int e3 = p1 + p2 * fx(0.765366865);
+        wide e2 = p1 + p3 * fx(-1.847759065);
+        wide e3 = p1 + p2 * fx(0.765366865);
         p2 = s0;
         p3 = s4;
-        int e0 = (p2 + p3) * 4096;
-        int e1 = (p2 - p3) * 4096;
+        wide e0 = (p2 + p3) * 4096;
+        wide e1 = (p2 - p3) * 4096;
         x0 = e0 + e3;
         x3 = e0 - e3;
         x1 = e1 + e2;
@@ -151,16 +156,16 @@ struct Idct1D {
 };
 
 void idct_block(const int *coef, uint8_t *out, int stride) {
-    int tmp[64];
+    wide tmp[64];
     for (int c = 0; c < 8; ++c) {
         const int *d = coef + c;
         if (!d[8] && !d[16] && !d[24] && !d[32] && !d[40] && !d[48] && !d[56]) {
-            int dc = d[0] * 4;
+            wide dc = (wide)d[0] * 4;
             for (int r = 0; r < 8; ++r) tmp[r * 8 + c] = dc;
             continue;
         }
         Idct1D k(d[0], d[8], d[16], d[24], d[32], d[40], d[48], d[56]);
-        int x0 = k.x0 + 512, x1 = k.x1 + 512, x2 = k.x2 + 512, x3 = k.x3 + 512;
+        wide x0 = k.x0 + 512, x1 = k.x1 + 512, x2 = k.x2 + 512, x3 = k.x3 + 512;
         tmp[0 * 8 + c] = (x0 + k.t3) >> 10;
         tmp[7 * 8 + c] = (x0 - k.t3) >> 10;
         tmp[1 * 8 + c] = (x1 + k.t2) >> 10;
@@ -171,11 +176,11 @@ void idct_block(const int *coef, uint8_t *out, int stride) {
         tmp[4 * 8 + c] = (x3 - k.t0) >> 10;
     }
     for (int r = 0; r < 8; ++r) {
-        const int *v = tmp + r * 8;
+        const wide *v = tmp + r * 8;
         uint8_t *o = out + r * stride;
         Idct1D k(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
-        const int bias = 65536 + (128 << 17);
-        int x0 = k.x0 + bias, x1 = k.x1 + bias, x2 = k.x2 + bias, x3 = k.x3 + bias;
+        const wide bias = 65536 + (128 << 17);
+        wide x0 = k.x0 + bias, x1 = k.x1 + bias, x2 = k.x2 + bias, x3 = k.x3 + bias;
         o[0] = clamp8((x0 + k.t3) >> 17);
         o[7] = clamp8((x0 - k.t3) >> 17);
         o[1] = clamp8((x1 + k.t2) >> 17);
@@ -204,6 +209,7 @@ Image decode_jpeg(const uint8_t *data, size_t size) {
         if (pos + 4 > size) throw std::runtime_error("JPEG: truncated before scan");
         if (data[pos] != 0xFF) throw std::runtime_error("JPEG: expected marker");
         while (pos < size && data[pos] == 0xFF) ++pos;
+        if (pos >= size) throw std::runtime_error("JPEG: truncated at a marker");
         uint8_t m = data[pos++];
         if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;
         if (m == 0xD9) throw std::runtime_error("JPEG: EOI before scan");
@@ -262,6 +268,7 @@ Image decode_jpeg(const uint8_t *data, size_t size) {
                 vmax = std::max(vmax, comps[c].v);
             }
             if (width <= 0 || height <= 0) throw std::runtime_error("JPEG: bad dimensions");
+            if ((long long)width * height > (1ll << 28)) throw std::runtime_error("JPEG: more than 2^28 pixels");
             have_frame = true;
         } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
             throw std::runtime_error("JPEG: only baseline/sequential Huffman JPEG is supported");
@@ -270,8 +277,10 @@ Image decode_jpeg(const uint8_t *data, size_t size) {
             restart_interval = be16(seg);
         } else if (m == 0xDA) {  // SOS
             if (!have_frame) throw std::runtime_error("JPEG: scan before frame header");
+            if (n < 1) throw std::runtime_error("JPEG: truncated SOS");
             int ns = seg[0];
             if (ns != (int)comps.size()) throw std::runtime_error("JPEG: non-interleaved scans are not supported");
+            if ((size_t)(1 + 2 * ns) > n) throw std::runtime_error("JPEG: truncated SOS");
             for (int s = 0; s < ns; ++s) {
                 int cid = seg[1 + 2 * s];
                 bool found = false;
@@ -279,6 +288,7 @@ Image decode_jpeg(const uint8_t *data, size_t size) {
                     if (c.id == cid) {
                         c.td = seg[2 + 2 * s] >> 4;
                         c.ta = seg[2 + 2 * s] & 15;
+                        if (c.td > 3 || c.ta > 3) throw std::runtime_error("JPEG: bad Huffman table id in scan");
                         found = true;
                     }
                 if (!found) throw std::runtime_error("JPEG: scan names an unknown component");
@@ -316,8 +326,9 @@ Image decode_jpeg(const uint8_t *data, size_t size) {
                     for (int bx = 0; bx < c.h; ++bx) {
                         std::memset(coef, 0, sizeof coef);
                         int t = decode_symbol(br, dc[c.td]);
+                        if (t > 11) throw std::runtime_error("JPEG: bad DC size");  // 8-bit samples: differences need <= 11 bits
                         int diff = t ? extend(br.bits(t), t) : 0;
-                        c.dc_pred += diff;
+                        c.dc_pred = std::max(-32768, std::min(32767, c.dc_pred + diff));
                         coef[0] = c.dc_pred * qt[c.tq][0];
                         for (int k = 1; k < 64;) {
                             int rs = decode_symbol(br, ac[c.ta]);
@@ -327,6 +338,7 @@ Image decode_jpeg(const uint8_t *data, size_t size) {
                                 k += 16;
                                 continue;
                             }
+                            if (s > 10) throw std::runtime_error("JPEG: bad AC size");  // 8-bit samples: <= 10 bits
                             k += r;
                             if (k > 63) throw std::runtime_error("JPEG: coefficient overrun");
                             int z = ZIGZAG[k];

@@ -312,6 +312,51 @@ def test_jpeg_420_and_ppm(tmp_path):
         load_image(tmp_path / "bad.jpg")
 
 
+def test_malformed_jpegs_are_errors_not_crashes(tmp_path):
+    """Texture files are untrusted input: truncated files, table ids and bit counts out of range, and random byte
+    damage in the headers or the entropy-coded data either decode to an image of the declared size or raise."""
+    good = open(os.path.join(ASSETS, "earthmap.jpg"), "rb").read()
+
+    def attempt(data, must_fail=False):
+        (tmp_path / "x.jpg").write_bytes(bytes(data))
+        try:
+            img = load_image(tmp_path / "x.jpg")
+        except V4RayError as e:
+            assert "JPEG" in str(e) or "decode" in str(e)
+            return False
+        assert not must_fail
+        assert img.ndim == 3 and img.shape[2] == 3 and img.dtype == np.uint8
+        return True
+
+    sos = good.index(b"\xff\xda")
+    ns = good[sos + 4]
+    assert ns == 3
+    for k in range(ns):                       # Huffman table ids 4..15 in the scan header
+        bad = bytearray(good)
+        bad[sos + 6 + 2 * k] = 0xF0 if k else 0x4F
+        attempt(bad, must_fail=True)
+    bad = bytearray(good)                     # a scan header shorter than its component list
+    bad[sos + 2:sos + 4] = (3).to_bytes(2, "big")
+    attempt(bad, must_fail=True)
+    dht = good.index(b"\xff\xc4")             # every DC symbol says "32 more bits"
+    bad = bytearray(good)
+    n_codes = sum(bad[dht + 5:dht + 21])
+    bad[dht + 21:dht + 21 + n_codes] = bytes([32]) * n_codes
+    attempt(bad, must_fail=True)
+    attempt(good[:2] + b"\xff" * 50, must_fail=True)     # fill bytes up to the end of the file
+    for cut in list(range(2, 700, 7)) + [len(good) // 2, len(good) - 1]:
+        attempt(good[:cut], must_fail=cut < sos + 14)    # inside the headers; a cut scan decodes to a partly grey image
+    rng = np.random.default_rng(11)
+    decoded = 0
+    for trial in range(120):
+        bad = bytearray(good)
+        region = sos + 14 if trial % 2 else len(bad)
+        for _ in range(int(rng.integers(1, 6))):
+            bad[int(rng.integers(2, region))] = int(rng.integers(0, 256))
+        decoded += attempt(bad)
+    assert decoded > 20                        # damage in the scan data usually still decodes (to a damaged image)
+
+
 # ---- RenderResult, renderer.rs:336-406 ----------------------------------------------------------------
 def test_render_result_tonemap_table():
     res = RenderResult(4, 1)
