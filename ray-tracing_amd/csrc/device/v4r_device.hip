@@ -67,10 +67,11 @@ struct Queues {
     float4 *rad;                // per path slot: radiance of the finished path
     SegCtr *ctr;                // [max_depth + 1]
     uint2 *spill;               // traversal stack overflow, [entry][global thread]
-    unsigned long long *stats;  // segments, nodes, prims, paths, shaded, texel fetches, wave node steps, wave leaf steps
+    unsigned long long *stats;  // segments, nodes, prims, paths, shaded, texel fetches, wave node steps, wave leaf steps; [8]: failed V4R_CHECKs
     uint32_t *shape_rays;       // packet-statistics rule of the light pdf: [pass of the batch][primitive], the rays of the segment being
                                 // traced whose closest hit is that primitive (Lambertian shapes only), counted up to V4R_PACKET_MANY_RAYS
     uint32_t spill_stride;
+    uint32_t spill_depth;       // entries per thread in the spill slab
     uint32_t cap;               // path slots per batch
     uint32_t npix;              // pixels per pass of the batch being rendered (path slot = pass of the batch * npix + pixel)
     uint32_t flags_offset;      // shape_rays[flags_offset + i] != 0: counter i has reached V4R_PACKET_MANY_RAYS and is no longer incremented
@@ -269,8 +270,13 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
     st.spill = Q.spill + (size_t)blockIdx.x * BLOCK + threadIdx.x;
     st.spill_stride = Q.spill_stride;
     st.sp = 0;
+#ifdef V4R_DEBUG_CHECKS
+    st.errors = Q.stats + 8;
+    st.spill_depth = (int)Q.spill_depth;
+#endif
     SegCtr *ctr = Q.ctr + seg;
-    const uint32_t n_in = second ? ctr->given_up : (PRIMARY ? A.n_paths : rays_in(Q, seg));
+    uint32_t n_in = second ? ctr->given_up : (PRIMARY ? A.n_paths : rays_in(Q, seg));
+    if (!V4R_CHECK(Q.stats + 8, CHECK_QUEUE_LENGTH, n_in <= Q.cap)) n_in = 0;
     float4 *const *rq = Q.ray[seg & 1u];
     const uint32_t npix = A.npix;
     // packet-statistics rule of the light pdf: the first levels count the rays that end on each Lambertian shape
@@ -356,8 +362,10 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
                         uint32_t full = 1u;
                         if (count_shape_rays) {
                             uint32_t pass = PRIMARY ? pass_in_batch : __float_as_uint(rq[1][i].z) / npix;
-                            n_rays += (size_t)pass * S.n_prims + best.prim;
-                            full = n_rays[Q.flags_offset];
+                            if (V4R_CHECK(Q.stats + 8, CHECK_RAY_COUNTER, (size_t)(pass + 1u) * S.n_prims <= Q.flags_offset)) {
+                                n_rays += (size_t)pass * S.n_prims + best.prim;
+                                full = n_rays[Q.flags_offset];
+                            }
                         }
                         const uint32_t info = S.prim_info[best.prim], cls = info >> 24;
                         if (info & PRIM_INFO_PLAIN_LIGHT) {
@@ -429,7 +437,7 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
             if (w != 0xFFFFFFFFu) {
                 uint32_t i = second ? Q.given_up[pos] : pos;
                 uint32_t k = w >> 16, idx = s_cnt[k] + (w & 0xFFFFu);
-                (k < (uint32_t)CLS_COUNT ? Q.hit[k] : Q.given_up)[idx] = i;
+                if (V4R_CHECK(Q.stats + 8, CHECK_QUEUE_INDEX, idx < Q.cap && i < Q.cap)) (k < (uint32_t)CLS_COUNT ? Q.hit[k] : Q.given_up)[idx] = i;
             }
         }
         __syncthreads();
@@ -568,7 +576,8 @@ V4R_DEV bool shade_hit(const SceneDev &S, const Queues &Q, const PathState &p, f
 template <int CLS, bool COUNT, bool NOISE>
 __global__ __launch_bounds__(BLOCK, NOISE ? V4R_SHADE_MIN_WAVES_NOISE : 1) void k_shade(SceneDev S, Queues Q, uint32_t seg) {
     SegCtr *ctr = Q.ctr + seg;
-    const uint32_t n_in = ctr->hit_count[CLS];
+    uint32_t n_in = ctr->hit_count[CLS];
+    if (!V4R_CHECK(Q.stats + 8, CHECK_QUEUE_LENGTH, n_in <= Q.cap)) n_in = 0;
     const uint32_t *hq = Q.hit[CLS];
     float4 *const *rq = Q.ray[seg & 1u];  // the rays k_trace just traced; the survivors go to the other queue
     float4 *const *out = Q.ray[(seg + 1u) & 1u];
@@ -581,6 +590,7 @@ __global__ __launch_bounds__(BLOCK, NOISE ? V4R_SHADE_MIN_WAVES_NOISE : 1) void 
         bool valid = i < n_in;
         uint32_t ii = valid ? i : n_in - 1u;
         uint32_t src = hq[ii];
+        if (!V4R_CHECK(Q.stats + 8, CHECK_QUEUE_INDEX, src < Q.cap)) src = 0;
         PathState p = unpack_ray(rq[0][src], rq[1][src], rq[2][src]);
         float4 dcol = Q.hitd[src];
         if (valid) n_shaded++;
@@ -590,6 +600,7 @@ __global__ __launch_bounds__(BLOCK, NOISE ? V4R_SHADE_MIN_WAVES_NOISE : 1) void 
         bool goes_on = shade_hit<CLS, NOISE>(S, Q, p, dcol, seg, fetched, q, rad);
         if (!valid) continue;  // a lane past the end of the queue shaded a copy of the last hit
         texel_fetches += fetched;
+        if (!V4R_CHECK(Q.stats + 8, CHECK_PATH_SLOT, p.slot < Q.cap) || !V4R_CHECK(Q.stats + 8, CHECK_NEXT_RAY, out_base + i < Q.cap)) continue;
         if (goes_on) store_ray(out, out_base + i, q);  // hit i of this class -> ray out_base + i of the next segment
         else Q.rad[p.slot] = rad;
     }
@@ -639,6 +650,10 @@ __global__ __launch_bounds__(BLOCK, NOISE ? V4R_TAIL_MIN_WAVES_NOISE : 1) void k
     st.spill = Q.spill + (size_t)blockIdx.x * BLOCK + threadIdx.x;
     st.spill_stride = Q.spill_stride;
     st.sp = 0;
+#ifdef V4R_DEBUG_CHECKS
+    st.errors = Q.stats + 8;
+    st.spill_depth = (int)Q.spill_depth;
+#endif
     const uint32_t n_in = rays_in(Q, seg0);
     float4 *const *rq = Q.ray[seg0 & 1u];
     TraceCounters cnt;
@@ -756,6 +771,10 @@ __global__ __launch_bounds__(BLOCK) void k_trace_rays(SceneDev S, Queues Q, uint
     st.spill = Q.spill + (size_t)blockIdx.x * BLOCK + threadIdx.x;
     st.spill_stride = Q.spill_stride;
     st.sp = 0;
+#ifdef V4R_DEBUG_CHECKS
+    st.errors = Q.stats + 8;
+    st.spill_depth = (int)Q.spill_depth;
+#endif
     uint32_t stride = gridDim.x * BLOCK;
     TraceCounters cnt;
     // the loop bound is wave-uniform: traverse() votes across the wave
@@ -1334,6 +1353,7 @@ int ensure_pipe(v4r_renderer *r, Pipe &pipe, size_t need, size_t n_passes) {
     HIP_TRY(hipMemsetAsync(Q.ctr, 0, r->ctr_bytes, pipe.stream));
     Q.stats = r->stats;
     Q.spill_stride = (size_t)r->grid_trace * BLOCK;
+    Q.spill_depth = r->spill_depth;
     if (int rc = alloc(&Q.spill, Q.spill_stride * std::max(r->spill_depth, 1u))) return rc;
     if (int rc = alloc(&Q.shape_rays, 2 * n_passes * r->S.n_prims)) return rc;  // counters, then their "full" flags
     pipe.count_passes = n_passes;
@@ -1379,6 +1399,7 @@ void carve_noalloc(v4r_renderer *r, int n_cu) {
         return true;
     };
     Q.spill_stride = (size_t)pipe.grid_trace * BLOCK;
+    Q.spill_depth = r->spill_depth;
     if (!take(&Q.spill, Q.spill_stride * std::max(r->spill_depth, 1u))) return;
     if (!take(&Q.ctr, (size_t)r->max_depth + 1)) return;
     if (r->S.packet_rule) {  // ray counters of the packet-statistics rule, for batches of up to NOALLOC_COUNTED_PASSES passes
@@ -1559,8 +1580,8 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     uint32_t stack_max = 3u * wide_depth + 1u;
     uint32_t spill_depth = stack_max > (uint32_t)LDS_DEPTH ? stack_max - LDS_DEPTH : 0;
     r->ctr_bytes = sizeof(SegCtr) * ((size_t)d->max_depth + 1);
-    if (int rc = r->alloc(&r->stats, 8)) return rc;
-    HIP_TRY(hipMemset(r->stats, 0, 64));
+    if (int rc = r->alloc(&r->stats, 16)) return rc;
+    HIP_TRY(hipMemset(r->stats, 0, 128));
     HIP_TRY(hipEventCreateWithFlags(&r->fork, hipEventDisableTiming));
     r->pipes.resize(n_pipes);
     r->max_depth = d->max_depth;
@@ -1672,6 +1693,15 @@ int run_batch(v4r_renderer *r, Pipe &pipe, uint64_t seed, uint32_t first_pass, u
     }
     PrimaryArgs primary{(uint32_t)seed, (uint32_t)(seed >> 32), first_pass, pass_stride, n_paths, band_pix, band_offset, order};
     pipe.Q.npix = band_pix;
+#ifdef V4R_DEBUG_CHECKS
+    // proof that a failed check is reported: the kernels are told a smaller capacity than the queues have
+    const uint32_t true_cap = pipe.Q.cap;
+    if (const char *env = std::getenv("V4R_DEBUG_CAP")) pipe.Q.cap = (uint32_t)std::max(0, std::atoi(env));
+    struct Restore {
+        uint32_t &cap, value;
+        ~Restore() { cap = value; }
+    } restore{pipe.Q.cap, true_cap};
+#endif
     pipe.Q.flags_offset = n_batch_passes * r->S.n_prims;
     if (r->S.packet_rule && n_batch_passes > pipe.count_passes) return set_error(V4R_E_INVALID, "internal: batch larger than the pipeline's ray counters");
     // segments 0 .. n_wavefront-1 run as one trace launch (or two) and one shading launch per class; one k_tail finishes the rest
@@ -1731,6 +1761,26 @@ int run_batch(v4r_renderer *r, Pipe &pipe, uint64_t seed, uint32_t first_pass, u
     HIP_TRY(hipEventRecord(pipe.done, pipe.stream));
     r->last_resolve = pipe.done;
     pipe.used = true;
+    return V4R_OK;
+}
+
+// Checked build: wait for the job and turn failed device-side bounds checks into an error.
+int report_checks(v4r_renderer *r) {
+#ifdef V4R_DEBUG_CHECKS
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    unsigned long long failed = 0;
+    HIP_TRY(hipMemcpy(&failed, r->stats + 8, sizeof failed, hipMemcpyDeviceToHost));
+    if (failed) {
+        HIP_TRY(hipMemset(r->stats + 8, 0, sizeof failed));
+        static const char *names[] = {"stack overflow", "stack underflow", "queue index", "queue length", "ray counter", "path slot", "next ray"};
+        std::string what;
+        for (int k = 0; k < 7; ++k)
+            if (failed >> k & 1ull) what += std::string(what.empty() ? "" : ", ") + names[k];
+        return set_error(V4R_E_HIP, "device bounds checks failed: " + what);
+    }
+#else
+    (void)r;
+#endif
     return V4R_OK;
 }
 
@@ -1836,7 +1886,7 @@ int v4r_render_rows(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_
     }
     if (int rc = join_pipes(r)) return rc;
     if (n_rows == r->S.height) r->n_passes += n_passes;
-    return V4R_OK;
+    return report_checks(r);
 }
 
 int v4r_render(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_t pass_stride, uint32_t n_passes) {
@@ -1868,7 +1918,7 @@ int v4r_render_noalloc(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint
         done += nb;
     }
     r->n_passes += n_passes;
-    return V4R_OK;
+    return report_checks(r);
 }
 
 int v4r_accum_bind(v4r_renderer *r, float *device_hwc) {

@@ -227,6 +227,17 @@ V4R_DEV void consider(const SceneDev &S, uint32_t prim_index, V3 o, V3 d, Best &
     }
 }
 
+// Bounds checks of a checked build (-DV4R_DEBUG_CHECKS, lib/libv4ray_hip_checked.so): an index that leaves its array is
+// not followed; its check's bit is raised in a device word that the host reads after the job and turns into an error.
+// `V4R_CHECK(errors, code, condition)` is true when the access may go ahead; without the flag it is the constant true.
+enum : int { CHECK_STACK_OVERFLOW = 0, CHECK_STACK_UNDERFLOW = 1, CHECK_QUEUE_INDEX = 2, CHECK_QUEUE_LENGTH = 3, CHECK_RAY_COUNTER = 4,
+             CHECK_PATH_SLOT = 5, CHECK_NEXT_RAY = 6 };
+#ifdef V4R_DEBUG_CHECKS
+#define V4R_CHECK(errors, code, condition) ((condition) ? true : (atomicOr((errors), 1ull << (code)), false))
+#else
+#define V4R_CHECK(errors, code, condition) true
+#endif
+
 // Stack of the traversal: the first LDS_DEPTH entries of each lane live in LDS (conflict-free:
 // entry e of thread t sits at [e][t]); deeper entries spill to a per-thread slab in HBM.
 #ifndef V4R_LDS_DEPTH
@@ -245,6 +256,7 @@ constexpr int TOP_LEVELS = V4R_TOP_LEVELS;
 constexpr int TOP_NODES = TOP_LEVELS == 4 ? 85 : (TOP_LEVELS == 3 ? 21 : (TOP_LEVELS == 2 ? 5 : 1));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4f lds_v4f;
+constexpr uint32_t TRAV_NONE_WORD = 0xFFFFFFFFu;  // "no entry" (see Wide)
 struct Stack {
     const lds_v4f *top = nullptr;  // 8 vectors per node, nodes 0 .. n_top-1; n_top = 0: no copy in LDS
     uint32_t n_top = 0;
@@ -253,6 +265,10 @@ struct Stack {
     uint2 *spill;      // this thread's column in the global slab: spill[e * spill_stride]
     size_t spill_stride;
     int sp;
+#ifdef V4R_DEBUG_CHECKS
+    unsigned long long *errors = nullptr;
+    int spill_depth = 0;  // entries of this thread's column in the slab
+#endif
     __device__ __forceinline__ void push(uint32_t node, float entry) {
         uint2 v = make_uint2(node, __float_as_uint(entry));
         if (sp < LDS_DEPTH) {
@@ -260,11 +276,17 @@ struct Stack {
             p->x = v.x;
             p->y = v.y;
         } else {
+#ifdef V4R_DEBUG_CHECKS
+            if (!V4R_CHECK(errors, CHECK_STACK_OVERFLOW, sp - LDS_DEPTH < spill_depth)) return;
+#endif
             spill[(size_t)(sp - LDS_DEPTH) * spill_stride] = v;
         }
         ++sp;
     }
     __device__ __forceinline__ uint2 pop() {
+#ifdef V4R_DEBUG_CHECKS
+        if (!V4R_CHECK(errors, CHECK_STACK_UNDERFLOW, sp > 0)) return make_uint2(TRAV_NONE_WORD, 0u);
+#endif
         --sp;
         uint2 v;
         if (sp < LDS_DEPTH) {
@@ -282,7 +304,7 @@ struct Stack {
 #define V4R_VOTE_NUM 1
 #define V4R_VOTE_DEN 2
 #endif
-constexpr uint32_t TRAV_NONE = 0xFFFFFFFFu;
+constexpr uint32_t TRAV_NONE = TRAV_NONE_WORD;
 #ifndef V4R_GIVE_UP_MIN_STEPS
 #define V4R_GIVE_UP_MIN_STEPS 3u  // node steps a wave makes before it may give rays up
 #endif
