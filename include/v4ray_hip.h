@@ -213,7 +213,7 @@ typedef struct v4r_renderer v4r_renderer;
  * is enabled; they feed the algorithmic-bytes figure of the roofline report. */
 typedef struct v4r_stats {
     uint64_t segments;     /* rays traced (one per path segment)         */
-    uint64_t nodes;        /* 64-byte BVH nodes fetched                  */
+    uint64_t nodes;        /* 128-byte 4-wide BVH nodes fetched          */
     uint64_t prims;        /* 48-byte primitive records intersected      */
     uint64_t paths;        /* camera paths started                       */
     uint64_t shaded;       /* hit records shaded                         */
@@ -307,7 +307,7 @@ int v4r_tonemap_u8(v4r_renderer *r, uint32_t n_passes, uint8_t *host_rgb);
  * Renderer::ray_color (src/renderer.rs:149-183) for depth-0 rays. */
 int v4r_trace_primary(v4r_renderer *r, uint32_t *host_prim_id, float *host_t);
 
-/* Trace n caller-supplied rays (origins and unit directions as n x 3 floats, optional time) and
+/* Trace n caller-supplied rays (origins and unit directions as n x 3 floats) and
  * return closest primitive / t per ray. `seed` keys the stochastic constant-medium test.
  * Maps to BVH::traverse + Hittable::hit (src/hittable/mod.rs:180-182). */
 int v4r_trace_rays(v4r_renderer *r, uint32_t n, const float *host_origin, const float *host_dir,
