@@ -74,6 +74,7 @@ def parse():
     ap.add_argument("--split", default="sample", choices=["sample", "tile"],
                     help="N > 1: rank r renders passes r, r+N, ... of the job (sample) or all passes of its band of rows (tile)")
     ap.add_argument("--c4-subdivide", type=int, default=2, help="midpoint subdivisions of bunny.obj in c4 (2: 79 488 triangles, 0: 4 968)")
+    ap.add_argument("--flags", type=int, default=0, help="scene flags (experiments: 4 = per-ray plane light pdf, 1 = bounded light pdf)")
     ap.add_argument("--no-side", action="store_true", help="skip the short random-spheres (c2) measurement added to the c4 line")
     return ap.parse_args()
 
@@ -271,7 +272,7 @@ def main():
     # the bunny's mesh transform is baked into its triangles on the host: the same geometry without a per-test
     # ray transform (tests/test_gpu_parity.py::test_primary_hits_pretransformed_bunny checks ids and t)
     extra = {"subdivide": args.c4_subdivide} if args.workload == "c4" and args.c4_subdivide != 2 else {}
-    scene = scenes.load(args.workload, width, height, pretransform_triangles=True, **extra)
+    scene = scenes.load(args.workload, width, height, pretransform_triangles=True, flags=args.flags, **extra)
     r = Renderer(scene.renderer_param, scene.camera_param, scene, device=local_rank)
     npix = width * height
     accum = torch.zeros(height, width, 3, dtype=torch.float32, device=f"cuda:{local_rank}")

@@ -1164,8 +1164,10 @@ void render_pass_packets(const v4r_scene_desc *s, uint64_t seed, uint32_t pass, 
         }
         if (rule == 3) {
             if (seg < PacketRule::COUNTED_LEVELS) {  // deeper levels reuse the counts of the last counted one
-                std::fill(shape_rays.begin(), shape_rays.end(), 0u);
-                for (const Order &o : order) shape_rays[o.shape]++;
+                // a shape that MANY_RAYS rays of the pass ended on at some level counts as full from that level on
+                for (uint32_t k = 0; k < s->n_prims; ++k) shape_rays[k] = shape_rays[k] >= PacketRule::MANY_RAYS ? PacketRule::MANY_RAYS : 0u;
+                for (const Order &o : order)
+                    if (shape_rays[o.shape] < PacketRule::MANY_RAYS) shape_rays[o.shape]++;
             }
             scattered.assign(order.size(), Scatter{});
             parallel_for((uint32_t)order.size(), n_threads, [&](uint32_t b, uint32_t e, int tid) {

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -74,6 +75,7 @@ struct Queues {
     uint32_t spill_depth;       // entries per thread in the spill slab
     uint32_t cap;               // path slots per batch
     uint32_t npix;              // pixels per pass of the batch being rendered (path slot = pass of the batch * npix + pixel)
+    float inv_npix;             // 1 / npix (pass_of_slot)
     uint32_t flags_offset;      // shape_rays[flags_offset + i] != 0: counter i has reached V4R_PACKET_MANY_RAYS and is no longer incremented
 };
 
@@ -191,6 +193,15 @@ V4R_DEV void ray_order(const RayOrder &R, uint32_t width, uint32_t npix, uint32_
     pixel = y * width + x;
 }
 
+// slot / npix for a path slot (= pass of the batch * npix + pixel, < 2^31) without the integer division: the float
+// quotient is off by at most one, which two comparisons repair.
+V4R_DEV uint32_t pass_of_slot(uint32_t slot, uint32_t npix, float inv_npix) {
+    uint32_t q = (uint32_t)((float)slot * inv_npix);
+    if ((unsigned long long)q * npix > slot) --q;
+    else if ((unsigned long long)(q + 1u) * npix <= slot) ++q;
+    return q;
+}
+
 // Rays queued for segment `seg` >= 1: one ray per hit that the scattering classes of the previous
 // segment shaded (lights never scatter, diffuse_light.rs).  Segment 0 traces one camera ray per path slot.
 V4R_DEV uint32_t rays_in(const Queues &Q, uint32_t seg) {
@@ -247,6 +258,7 @@ V4R_DEV void stage_tree_top(const SceneDev &S, v4f *s_top, Stack &st) {
 struct PrimaryArgs {
     uint32_t seed_lo, seed_hi, first_pass, pass_stride, n_paths;
     uint32_t npix;          // pixels of the band of rows being rendered (the whole image for v4r_render)
+    float inv_npix;         // 1 / npix, rounded down (pass_of_slot)
     uint32_t pixel_offset;  // index of the band's first pixel in the image
     RayOrder order;         // over the band
 };
@@ -308,6 +320,7 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
                 const uint32_t ii = i;
                 V3 o, d;
                 uint32_t pass_in_batch = 0, pixel = 0;  // PRIMARY only
+                uint32_t slot = 0;                       // later segments, while rays are counted per shape
                 if (PRIMARY) {
                     // Renderer::sample + Camera::get_ray for queue entry ii (see ray_order); the ray record is
                     // written further down, and only if the ray hits something: a miss ends the path here
@@ -317,9 +330,15 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
                     camera_ray(S, pixel + A.pixel_offset, segment_key(k0, k1, 0u), false, o, d);
                 } else {
                     float4 a = rq[0][ii];
-                    float2 b = *reinterpret_cast<const float2 *>(&rq[1][ii]);
                     o = v3(a.x, a.y, a.z);
-                    d = v3(a.w, b.x, b.y);
+                    if (count_shape_rays) {  // the path slot comes with the direction: the ray counter is addressed by its pass
+                        float4 b = rq[1][ii];
+                        d = v3(a.w, b.x, b.y);
+                        slot = __float_as_uint(b.z);
+                    } else {
+                        float2 b = *reinterpret_cast<const float2 *>(&rq[1][ii]);
+                        d = v3(a.w, b.x, b.y);
+                    }
                 }
                 Best best;
                 best.t = V4R_INF;
@@ -354,14 +373,15 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
                     if (COUNT) n_traced++;
                     if (best.prim != NO_PRIM) {
                         // Packet-statistics rule of the light pdf: count the pass's rays per Lambertian shape they end on.  A
-                        // counter that reaches V4R_PACKET_MANY_RAYS raises its "full" flag and is left alone from then on
-                        // (walls would otherwise serialise the chip on a handful of addresses; from that count on the rule
-                        // treats every packet as full).  The flag is read and written with plain accesses: a stale 0 only
-                        // costs one more increment.  Its load is issued beside the primitive's class.
+                        // counter that reaches V4R_PACKET_MANY_RAYS raises its "full" flag and is left alone from then on,
+                        // at this level and the deeper ones of the batch (walls would otherwise serialise the chip on a
+                        // handful of addresses -- every launch anew, until each compute unit has seen the flag; from that
+                        // count on the rule treats every packet as full).  The flag is read and written with plain
+                        // accesses: a stale 0 only costs one more increment.  Its load is issued beside the primitive's class.
                         uint32_t *n_rays = Q.shape_rays;
                         uint32_t full = 1u;
                         if (count_shape_rays) {
-                            uint32_t pass = PRIMARY ? pass_in_batch : __float_as_uint(rq[1][i].z) / npix;
+                            uint32_t pass = PRIMARY ? pass_in_batch : pass_of_slot(slot, npix, A.inv_npix);
                             if (V4R_CHECK(Q.stats + 8, CHECK_RAY_COUNTER, (size_t)(pass + 1u) * S.n_prims <= Q.flags_offset)) {
                                 n_rays += (size_t)pass * S.n_prims + best.prim;
                                 full = n_rays[Q.flags_offset];
@@ -386,9 +406,15 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
                         } else {
                             Q.hitd[i] = make_float4(best.t, __uint_as_float(best.prim), best.u, best.v);
                             dest = cls;
-                            if (count_shape_rays && (cls == (uint32_t)CLS_LAMBERT || cls == (uint32_t)CLS_LAMBERT_NOISE) && full == 0u &&
-                                atomicAdd(n_rays, 1u) + 1u >= V4R_PACKET_MANY_RAYS)
-                                n_rays[Q.flags_offset] = 1u;
+                            if (count_shape_rays && (cls == (uint32_t)CLS_LAMBERT || cls == (uint32_t)CLS_LAMBERT_NOISE) && full == 0u) {
+                                // A shape too small to expect many rays (a mesh triangle) is counted without waiting for
+                                // the counter's value: it will not fill, and a few percent of the rays end on such shapes,
+                                // so waiting would hold nearly every wave of the later segments for a trip to memory.
+                                // (The size class is a guess from the shape's share of the scene's area; a wrong guess
+                                // costs time -- contended or waited-for increments -- never a wrong count.)
+                                if (info & PRIM_INFO_SMALL) atomicAdd(n_rays, 1u);
+                                else if (atomicAdd(n_rays, 1u) + 1u >= V4R_PACKET_MANY_RAYS) n_rays[Q.flags_offset] = 1u;
+                            }
                             if (PRIMARY) {
                                 PathState p;
                                 p.o = o;
@@ -472,7 +498,10 @@ V4R_DEV bool shade_hit(const SceneDev &S, const Queues &Q, const PathState &p, f
     // packet-statistics rule of the light pdf: the rays of the path's pass that ended on this shape at this level (k_trace
     // counted them); fetched first, beside the records above
     uint32_t n_rays = 0u;
-    if ((CLS == CLS_LAMBERT || CLS == CLS_LAMBERT_NOISE) && S.packet_rule) n_rays = Q.shape_rays[(size_t)(p.slot / Q.npix) * S.n_prims + prim];
+    if ((CLS == CLS_LAMBERT || CLS == CLS_LAMBERT_NOISE) && S.packet_rule) {
+        const uint32_t *counter = Q.shape_rays + (size_t)pass_of_slot(p.slot, Q.npix, Q.inv_npix) * S.n_prims + prim;
+        n_rays = counter[0];  // a counter that filled up at a shallower level was left standing (k_restart_counters)
+    }
     if (CLS == CLS_LIGHT) {  // material/diffuse_light.rs:19-22; scatter() is the default None
         HitD h = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, false);
         V3 e = texture_value<NOISE>(
@@ -719,6 +748,14 @@ __global__ __launch_bounds__(BLOCK, NOISE ? V4R_TAIL_MIN_WAVES_NOISE : 1) void k
     }
 }
 
+// Between two counted levels of a batch: the ray counters go back to zero, except those that have filled up (their shapes
+// count as full at every deeper level, and the shading reads that from the standing count).
+__global__ __launch_bounds__(BLOCK) void k_restart_counters(uint32_t *counters, size_t n) {
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride)
+        if (counters[i] < V4R_PACKET_MANY_RAYS) counters[i] = 0u;
+}
+
 // max_depth = 0 (renderer.rs:128-130): ray_color returns `environment` before it traces anything.
 __global__ __launch_bounds__(BLOCK) void k_fill_rad(Queues Q, uint32_t n, float r, float g, float b) {
     uint32_t stride = gridDim.x * BLOCK;
@@ -947,7 +984,7 @@ int validate(const v4r_scene_desc *d, uint32_t &depth_out) {
     if (int rc = need(d->images, d->n_images, "images")) return rc;
     if (int rc = need(d->perlin, d->n_perlin, "perlin")) return rc;
     if (int rc = need(d->lights, d->n_lights, "lights")) return rc;
-    if (d->n_materials > 0xFFFFFu) return set_error(V4R_E_LIMIT, "too many materials");
+    if (d->n_materials > 0x7FFFFu) return set_error(V4R_E_LIMIT, "too many materials");
 
     // BVH: n-1 interior nodes for n >= 2 primitives, every primitive reachable exactly once.
     if (d->n_prims <= 1) {
@@ -1032,6 +1069,31 @@ uint32_t class_of(const v4r_scene_desc *d, const v4r_material &m) {
         case V4R_MAT_DIELECTRIC: return CLS_DIELECTRIC;
         default: return CLS_ISOTROPIC;
     }
+}
+
+// Surface area of a primitive in world space (0 for a constant medium): only used to guess which shapes few rays reach.
+double surface_area(const v4r_scene_desc *d, const v4r_prim &pr) {
+    double a = 0.0;
+    switch (pr.type & V4R_PRIM_TYPE_MASK) {
+        case V4R_PRIM_SPHERE: a = 4.0 * 3.14159265358979323846 * (double)pr.f[3] * (double)pr.f[3]; break;
+        case V4R_PRIM_XY_RECT:
+        case V4R_PRIM_YZ_RECT:
+        case V4R_PRIM_ZX_RECT: a = ((double)pr.f[1] - (double)pr.f[0]) * ((double)pr.f[3] - (double)pr.f[2]); break;
+        case V4R_PRIM_TRIANGLE: {
+            const float *e = pr.f + 3;  // the two edge vectors
+            double cx = (double)e[1] * e[5] - (double)e[2] * e[4], cy = (double)e[2] * e[3] - (double)e[0] * e[5], cz = (double)e[0] * e[4] - (double)e[1] * e[3];
+            a = 0.5 * std::sqrt(cx * cx + cy * cy + cz * cz);
+            break;
+        }
+        default: return 0.0;
+    }
+    if (pr.xform != V4R_NO_XFORM) {  // the area scale of an affine map, taken as the 2/3 power of its volume scale
+        const float *m = d->xforms[pr.xform].fwd;
+        double det = (double)m[0] * ((double)m[4] * m[8] - (double)m[5] * m[7]) - (double)m[1] * ((double)m[3] * m[8] - (double)m[5] * m[6]) +
+                     (double)m[2] * ((double)m[3] * m[7] - (double)m[4] * m[6]);
+        a *= std::cbrt(det * det);
+    }
+    return a == a && a > 0.0 ? a : 0.0;
 }
 
 template <class K>
@@ -1457,12 +1519,21 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     }
     if (int rc = r->upload(&S.prims, (const float4 *)d->prims, (size_t)d->n_prims * 3)) return rc;
     std::vector<uint32_t> info(d->n_prims);
+    // shapes expected to receive fewer than 32 rays of a pass (their share of the scene's surface area x the pixels)
+    std::vector<uint8_t> small(d->n_prims, 0);
+    {
+        std::vector<double> area(d->n_prims);
+        double total = 0.0;
+        for (uint32_t i = 0; i < d->n_prims; ++i) total += area[i] = surface_area(d, d->prims[i]);
+        const double npix = (double)d->width * (double)d->height;
+        for (uint32_t i = 0; i < d->n_prims; ++i) small[i] = total > 0.0 && npix * area[i] < 32.0 * total;
+    }
     bool plain_lights = true;
     if (const char *env = std::getenv("V4R_PLAIN_LIGHTS")) plain_lights = std::atoi(env) != 0;
     for (uint32_t i = 0; i < d->n_prims; ++i) {
         const v4r_material &mat = d->materials[d->prim_material[i]];
         uint32_t cls = class_of(d, mat);
-        info[i] = d->prim_material[i] | (cls << 24);
+        info[i] = d->prim_material[i] | (cls << 24) | (small[i] ? PRIM_INFO_SMALL : 0u);
         // a one-colour light on an untransformed rectangle ends its paths inside k_trace (no queue, no shading launch)
         const v4r_prim &pr = d->prims[i];
         const uint32_t kind = pr.type & V4R_PRIM_TYPE_MASK;
@@ -1691,8 +1762,9 @@ int run_batch(v4r_renderer *r, Pipe &pipe, uint64_t seed, uint32_t first_pass, u
         order.npix_tiled = order.tiled_w * order.tiled_h;
         order.full_groups = n_batch_passes >> lp;
     }
-    PrimaryArgs primary{(uint32_t)seed, (uint32_t)(seed >> 32), first_pass, pass_stride, n_paths, band_pix, band_offset, order};
+    PrimaryArgs primary{(uint32_t)seed, (uint32_t)(seed >> 32), first_pass, pass_stride, n_paths, band_pix, 1.0f / (float)band_pix, band_offset, order};
     pipe.Q.npix = band_pix;
+    pipe.Q.inv_npix = 1.0f / (float)band_pix;
 #ifdef V4R_DEBUG_CHECKS
     // proof that a failed check is reported: the kernels are told a smaller capacity than the queues have
     const uint32_t true_cap = pipe.Q.cap;
@@ -1733,8 +1805,14 @@ int run_batch(v4r_renderer *r, Pipe &pipe, uint64_t seed, uint32_t first_pass, u
         v4r_renderer::EventPair *pair = nullptr;
         if (int rc = bracket_begin(V4R_PROFILE_TRACE, pair)) return rc;
         uint32_t launches = 1;
-        if (!tail && r->S.packet_rule && seg < V4R_PACKET_COUNTED_LEVELS)  // deeper levels reuse the counts of the last counted one
-            HIP_TRY(hipMemsetAsync(pipe.Q.shape_rays, 0, 2 * (size_t)n_batch_passes * r->S.n_prims * sizeof(uint32_t), pipe.stream));
+        // the counters start every counted level at zero (deeper levels reuse the counts of the last counted one); the "full"
+        // flags behind them are cleared once per batch: a shape that filled up at one level counts as full at the deeper ones
+        if (!tail && r->S.packet_rule && seg < V4R_PACKET_COUNTED_LEVELS)
+        {
+            const size_t n_counters = (size_t)n_batch_passes * r->S.n_prims;
+            if (seg == 0) HIP_TRY(hipMemsetAsync(pipe.Q.shape_rays, 0, 2 * n_counters * sizeof(uint32_t), pipe.stream));
+            else hipLaunchKernelGGL(k_restart_counters, dim3(r->grid_stream), dim3(BLOCK), 0, pipe.stream, pipe.Q.shape_rays, n_counters);
+        }
         if (tail) launch_tail(r, pipe, seg);  // timed with the trace launches: nearly all of it is traversal
         else launches = launch_trace(r, pipe, seg, primary);
         if (int rc = bracket_end(pair, launches)) return rc;

@@ -20,7 +20,8 @@ enum {
 };
 
 constexpr uint32_t NO_PRIM = 0xFFFFFFFFu;
-// prim_info word: material index (20 bits) | flags | shading class << 24
+// prim_info word: material index (19 bits) | flags | shading class << 24
+constexpr uint32_t PRIM_INFO_SMALL = 1u << 19;        // the shape is too small to expect more than a few rays of a pass (k_trace's ray counters)
 constexpr uint32_t PRIM_INFO_PLAIN_LIGHT = 1u << 23;  // one-colour DiffuseLight on an untransformed rectangle: k_trace ends the path itself
 constexpr uint32_t PRIM_INFO_POSITIVE = 1u << 22;     // ... whose outward normal points along +axis
 constexpr uint32_t PRIM_INFO_AXIS_SHIFT = 20;         // ... axis of that normal (2 bits)
