@@ -105,11 +105,13 @@ def cpu_baseline(desc, npix, seed):
     except (AttributeError, OSError):
         usable = threads
     oracle.render(desc, 1, seed=seed, threads=threads, pixel_stride=64)  # page in, start the threads once
+    # whole passes run concurrently, one per thread, as the reference runs them (src/main.rs:56-63)
+    passes = threads
     t0 = time.perf_counter()
-    oracle.render(desc, 1, seed=seed, threads=threads)
+    oracle.render(desc, passes, seed=seed, threads=threads)
     dt = time.perf_counter() - t0
-    passes = max(1, min(64, int(round(2.0 / max(dt, 1e-3)))))  # ~2 s of wall time on every thread
-    if passes > 1:
+    if dt < 1.0:  # a fast host: ~2 s of wall time on every thread
+        passes = threads * max(2, min(16, int(round(2.0 / max(dt, 1e-3)))))
         t0 = time.perf_counter()
         oracle.render(desc, passes, seed=seed, threads=threads)
         dt = time.perf_counter() - t0

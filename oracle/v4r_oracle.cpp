@@ -1291,17 +1291,22 @@ int v4o_render(const v4r_scene_desc *s, uint64_t seed, uint32_t first_pass, uint
     const bool packet_rule = s->n_lights != 0 && !(s->flags & (V4R_FLAG_BOUNDED_LIGHT_PDF | V4R_FLAG_PLANE_LIGHT_PDF));
     if (mode == 2 || mode == 3 || (packet_rule && pixel_stride == 1)) {  // whole passes, breadth first
         const int rule = mode == 2 ? 2 : 3, trace_mode = mode == 1 ? 1 : 0;
-        if (n_threads > 1 && n_passes > 1 && npix <= (1u << 18)) {
-            // small image: one pass per thread, each into its own buffer; a pass adds exactly one term per pixel, so adding
-            // the buffers in pass order gives the bits of the sequential loop
-            std::vector<std::vector<float>> buf((size_t)n_threads, std::vector<float>((size_t)npix * 3));
-            std::vector<std::vector<Counters>> own((size_t)n_threads, std::vector<Counters>(1));
-            for (uint32_t k0 = 0; k0 < n_passes; k0 += (uint32_t)n_threads) {
-                const uint32_t group = std::min<uint32_t>((uint32_t)n_threads, n_passes - k0);
+        // Whole passes run concurrently, as the reference runs them (main.rs:56-63: one task per pass): `outer` passes at a
+        // time, each on `inner` threads and into its own buffer; a pass adds exactly one term per pixel, so adding the
+        // buffers in pass order gives the bits of a sequential loop.  `outer` is bounded by the passes asked for and by
+        // the memory the per-pass ray lists take (about 250 bytes per pixel).
+        const size_t budget = (size_t)24 << 30, per_pass = (size_t)npix * 250 + 1;
+        const uint32_t outer = (uint32_t)std::max<size_t>(1, std::min<size_t>(std::min<size_t>((size_t)n_threads, n_passes), budget / per_pass));
+        if (outer > 1) {
+            const int inner = std::max(1, n_threads / (int)outer);
+            std::vector<std::vector<float>> buf(outer, std::vector<float>((size_t)npix * 3));
+            std::vector<std::vector<Counters>> own(outer, std::vector<Counters>((size_t)inner));
+            for (uint32_t k0 = 0; k0 < n_passes; k0 += outer) {
+                const uint32_t group = std::min<uint32_t>(outer, n_passes - k0);
                 std::vector<std::thread> threads;
                 auto one = [&](uint32_t t) {
                     std::fill(buf[t].begin(), buf[t].end(), 0.0f);
-                    render_pass_packets(s, seed, first_pass + (k0 + t) * pass_stride, buf[t].data(), 1, own[t], rule, trace_mode, &wide);
+                    render_pass_packets(s, seed, first_pass + (k0 + t) * pass_stride, buf[t].data(), inner, own[t], rule, trace_mode, &wide);
                 };
                 for (uint32_t t = 1; t < group; ++t) threads.emplace_back(one, t);
                 one(0);
@@ -1309,7 +1314,8 @@ int v4o_render(const v4r_scene_desc *s, uint64_t seed, uint32_t first_pass, uint
                 for (uint32_t t = 0; t < group; ++t)
                     for (size_t q = 0; q < (size_t)npix * 3; ++q) accum[q] += buf[t][q];
             }
-            for (int t = 0; t < n_threads; ++t) counters[(size_t)t].add(own[(size_t)t][0]);
+            for (uint32_t t = 0; t < outer; ++t)
+                for (int k = 0; k < inner; ++k) counters[0].add(own[t][(size_t)k]);
         } else {
             for (uint32_t k = 0; k < n_passes; ++k)
                 render_pass_packets(s, seed, first_pass + k * pass_stride, accum, n_threads, counters, rule, trace_mode, &wide);
