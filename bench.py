@@ -81,17 +81,21 @@ def parse():
 
 def queue_bytes(stats):
     """Bytes each kernel group must move through HBM for the counted work (queue records only).
-    k_trace: per ray segment one 48-B ray record (read from the queue; a camera ray is generated in registers and
-    written instead), per hit a 16-B hit record + a 4-B class-queue index written, per miss a 16-B radiance slot.
-    k_shade: per hit the index, the ray and the hit record read, then the scattered ray (48 B) or, when the path
-    ends there, its radiance slot (16 B) written.  k_resolve: a 16-B radiance slot read per path, the fp32 RGB
-    accumulator read and written once per pixel and batch."""
-    segs, hits, paths = stats["segments"], stats["shaded"], stats["paths"]
+    k_trace: per ray segment the 32 B of a ray record that hold origin, direction and path slot (read from the queue; a
+    camera ray is generated in registers and its 48-B record written instead, when it hits), per queued hit a 16-B hit
+    record + a 4-B class-queue index written, per miss or hit on a plain light a 16-B radiance slot written and the
+    ray's throughput read.  k_shade: per queued hit the index, the ray and the hit record
+    read, then the scattered ray (48 B) or, when the path ends there, its radiance slot (16 B) written.  k_resolve: a
+    16-B radiance slot read per path, the fp32 RGB accumulator read and written once per pixel and batch."""
+    segs, hits, paths, lights = stats["segments"], stats["shaded"], stats["paths"], stats.get("ended_on_light", 0)
     misses = segs - hits
-    scattered = segs - paths           # every non-camera segment was written by a shading launch
-    ended_in_shade = hits - scattered   # lights, exhausted depth budgets
-    return {"trace": segs * RAY_RECORD + hits * (HIT_RECORD + QUEUE_INDEX) + misses * RADIANCE,
-            "shade": hits * (QUEUE_INDEX + RAY_RECORD + HIT_RECORD) + scattered * RAY_RECORD + ended_in_shade * RADIANCE,
+    queued = hits - lights              # hits that a shading launch sees
+    scattered = segs - paths            # every non-camera segment was written by a shading launch
+    ended_in_shade = queued - scattered  # other lights, exhausted depth budgets
+    ended_in_trace = misses + lights
+    # (camera rays that miss write no record and later enders also read 16 B of throughput: the two roughly cancel)
+    return {"trace": (segs - paths) * 32 + paths * RAY_RECORD + queued * (HIT_RECORD + QUEUE_INDEX) + ended_in_trace * RADIANCE,
+            "shade": queued * (QUEUE_INDEX + RAY_RECORD + HIT_RECORD) + scattered * RAY_RECORD + ended_in_shade * RADIANCE,
             "resolve": paths * RADIANCE}
 
 

@@ -220,6 +220,7 @@ typedef struct v4r_stats {
     uint64_t texel_fetches;/* image-texture texels fetched               */
     uint64_t wave_node_steps; /* times a 64-lane wave executed the node step: nodes / (64 * this) = lane utilisation */
     uint64_t wave_leaf_steps; /* times a wave executed the primitive test: prims / (64 * this) = lane utilisation  */
+    uint64_t ended_on_light;  /* of `shaded`: hits on one-colour rectangle lights that the trace kernel finished itself */
 } v4r_stats;
 
 /* ---- entry points ------------------------------------------------------------------------- */

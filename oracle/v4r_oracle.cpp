@@ -1296,9 +1296,10 @@ int v4o_render(const v4r_scene_desc *s, uint64_t seed, uint32_t first_pass, uint
         // buffers in pass order gives the bits of a sequential loop.  `outer` is bounded by the passes asked for and by
         // the memory the per-pass ray lists take (about 250 bytes per pixel).
         const size_t budget = (size_t)24 << 30, per_pass = (size_t)npix * 250 + 1;
-        const uint32_t outer = (uint32_t)std::max<size_t>(1, std::min<size_t>(std::min<size_t>((size_t)n_threads, n_passes), budget / per_pass));
+        const uint32_t most = (uint32_t)std::max<size_t>(1, std::min<size_t>(std::min<size_t>((size_t)n_threads, n_passes), budget / per_pass));
+        const int inner = std::max(1, (n_threads + (int)most - 1) / (int)most);           // threads per pass
+        const uint32_t outer = std::min<uint32_t>(most, (uint32_t)((n_threads + inner - 1) / inner));  // passes at a time
         if (outer > 1) {
-            const int inner = std::max(1, n_threads / (int)outer);
             std::vector<std::vector<float>> buf(outer, std::vector<float>((size_t)npix * 3));
             std::vector<std::vector<Counters>> own(outer, std::vector<Counters>((size_t)inner));
             for (uint32_t k0 = 0; k0 < n_passes; k0 += outer) {

@@ -475,6 +475,7 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
             atomicAdd(&Q.stats[1], n);
             atomicAdd(&Q.stats[2], q);
             atomicAdd(&Q.stats[4], l);  // lights shaded here count as shaded hits
+            atomicAdd(&Q.stats[9], l);
             atomicAdd(&Q.stats[6], (unsigned long long)cnt.wave_steps);
             atomicAdd(&Q.stats[7], (unsigned long long)cnt.wave_leaves);
         }
@@ -2144,7 +2145,7 @@ int v4r_stats_read(v4r_renderer *r, v4r_stats *out, int reset) {
     std::lock_guard<std::recursive_mutex> hold(r->mu);
     HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(hipStreamSynchronize(r->stream));
-    unsigned long long h[8];
+    unsigned long long h[10];
     HIP_TRY(hipMemcpy(h, r->stats, sizeof h, hipMemcpyDeviceToHost));
     out->segments = h[0];
     out->nodes = h[1];
@@ -2154,8 +2155,10 @@ int v4r_stats_read(v4r_renderer *r, v4r_stats *out, int reset) {
     out->texel_fetches = h[5];
     out->wave_node_steps = h[6];
     out->wave_leaf_steps = h[7];
+    out->ended_on_light = h[9];
     if (reset) {
         HIP_TRY(hipMemsetAsync(r->stats, 0, 64, r->stream));  // ordered before whatever is rendered next
+        HIP_TRY(hipMemsetAsync(r->stats + 9, 0, 8, r->stream));
         HIP_TRY(hipStreamSynchronize(r->stream));
     }
     return V4R_OK;

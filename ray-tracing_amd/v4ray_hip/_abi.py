@@ -91,7 +91,7 @@ class SceneDesc(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("segments", C.c_uint64), ("nodes", C.c_uint64), ("prims", C.c_uint64), ("paths", C.c_uint64),
                 ("shaded", C.c_uint64), ("texel_fetches", C.c_uint64),
-                ("wave_node_steps", C.c_uint64), ("wave_leaf_steps", C.c_uint64)]
+                ("wave_node_steps", C.c_uint64), ("wave_leaf_steps", C.c_uint64), ("ended_on_light", C.c_uint64)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}

@@ -44,7 +44,7 @@ def test_struct_sizes_match_the_header():
     assert C.sizeof(_abi.TriShading) == 64 and C.sizeof(_abi.Medium) == 16
     assert C.sizeof(_abi.Material) == 32 and C.sizeof(_abi.Texture) == 32 and C.sizeof(_abi.Image) == 16
     assert C.sizeof(_abi.Perlin) == 256 * 12 + 768 and C.sizeof(_abi.Camera) == 84
-    assert C.sizeof(_abi.Stats) == 64
+    assert C.sizeof(_abi.Stats) == 72
 
 
 def test_device_entry_points_reject_null_without_a_gpu():
