@@ -111,7 +111,8 @@ int v4rh_image_load(const char *path, uint32_t *width, uint32_t *height, uint8_t
 
 /* RenderResult::get_raw arithmetic on host data (src/renderer.rs:378-402): sums / n -> u8. */
 int v4rh_tonemap_u8(const float *sums, uint64_t n_floats, uint32_t n_passes, uint8_t *out);
-/* Write a 24-bit BMP or binary PPM (by extension) of an RGB image whose row 0 is the top. */
+/* Write an RGB image whose row 0 is the top; the format follows the extension like `image::save` (src/main.rs:70-72):
+ * .png, .ppm, .tga, otherwise a 24-bit BMP; extensions of formats this writer lacks (.jpg ...) are an error. */
 int v4rh_write_image(const char *path, const uint8_t *rgb, uint32_t width, uint32_t height);
 
 /* Accumulator checkpoint: a restartable image of RenderResult (src/renderer.rs:336-340: the fp32

@@ -1,4 +1,6 @@
 // extern "C" surface of the host-side scene pipeline (see include/v4ray_host.h).
+#include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -376,8 +378,98 @@ int v4rh_write_image(const char *path, const uint8_t *rgb, uint32_t width, uint3
         std::string p(path);
         std::ofstream f(p, std::ios::binary);
         if (!f) throw std::runtime_error("cannot open output image: " + p);
-        bool ppm = p.size() >= 4 && p.compare(p.size() - 4, 4, ".ppm") == 0;
-        if (ppm) {
+        // the format follows the file name's extension, as `image::save` does for the reference (src/main.rs:70-72):
+        // .png, .ppm, .tga, anything else (.bmp) a 24-bit BMP; a format this writer lacks (.jpg, ...) is an error
+        auto ends_with = [&](const char *ext) {
+            size_t n = std::strlen(ext);
+            if (p.size() < n) return false;
+            for (size_t k = 0; k < n; ++k)
+                if (std::tolower((unsigned char)p[p.size() - n + k]) != ext[k]) return false;
+            return true;
+        };
+        for (const char *ext : {".jpg", ".jpeg", ".gif", ".tif", ".tiff", ".webp", ".exr", ".hdr"})
+            if (ends_with(ext)) throw std::runtime_error("output format not supported (use .png, .bmp, .ppm or .tga): " + p);
+        bool ppm = ends_with(".ppm");
+        if (ends_with(".png")) {
+            // PNG, 8-bit RGB, filter 0 on every row, zlib stream of stored (uncompressed) deflate blocks
+            auto put_be32 = [](std::vector<uint8_t> &v, uint32_t x) {
+                for (int sh = 24; sh >= 0; sh -= 8) v.push_back((uint8_t)(x >> sh));
+            };
+            static uint32_t crc_table[256];
+            static bool have_table = false;
+            if (!have_table) {
+                for (uint32_t n = 0; n < 256; ++n) {
+                    uint32_t c = n;
+                    for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+                    crc_table[n] = c;
+                }
+                have_table = true;
+            }
+            auto chunk = [&](const char *type, const std::vector<uint8_t> &data) {
+                std::vector<uint8_t> out;
+                put_be32(out, (uint32_t)data.size());
+                out.insert(out.end(), type, type + 4);
+                out.insert(out.end(), data.begin(), data.end());
+                uint32_t c = 0xFFFFFFFFu;
+                for (size_t k = 4; k < out.size(); ++k) c = crc_table[(c ^ out[k]) & 255u] ^ (c >> 8);
+                put_be32(out, c ^ 0xFFFFFFFFu);
+                f.write((const char *)out.data(), (std::streamsize)out.size());
+            };
+            const uint8_t magic[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+            f.write((const char *)magic, 8);
+            std::vector<uint8_t> ihdr;
+            put_be32(ihdr, width);
+            put_be32(ihdr, height);
+            for (uint8_t b : {8, 2, 0, 0, 0}) ihdr.push_back(b);  // bit depth, colour type RGB, deflate, adaptive filtering, no interlace
+            chunk("IHDR", ihdr);
+            std::vector<uint8_t> raw;
+            raw.reserve((size_t)height * ((size_t)width * 3 + 1));
+            for (uint32_t y = 0; y < height; ++y) {
+                raw.push_back(0);
+                raw.insert(raw.end(), rgb + (size_t)y * width * 3, rgb + (size_t)(y + 1) * width * 3);
+            }
+            std::vector<uint8_t> z = {0x78, 0x01};
+            uint32_t a = 1, b = 0;  // Adler-32 of the raw data
+            for (size_t off = 0; off < raw.size() || off == 0;) {
+                size_t n = std::min<size_t>(65535, raw.size() - off);
+                z.push_back(off + n >= raw.size() ? 1 : 0);
+                z.push_back((uint8_t)n);
+                z.push_back((uint8_t)(n >> 8));
+                z.push_back((uint8_t)~n);
+                z.push_back((uint8_t)(~n >> 8));
+                z.insert(z.end(), raw.begin() + (std::ptrdiff_t)off, raw.begin() + (std::ptrdiff_t)(off + n));
+                for (size_t k = off; k < off + n; ++k) {
+                    a = (a + raw[k]) % 65521u;
+                    b = (b + a) % 65521u;
+                }
+                off += n;
+                if (n == 0) break;
+            }
+            put_be32(z, (b << 16) | a);
+            chunk("IDAT", z);
+            chunk("IEND", {});
+        } else if (ends_with(".tga")) {  // uncompressed true-colour TGA, top-left origin, BGR
+            uint8_t hdr[18] = {0};
+            hdr[2] = 2;
+            hdr[12] = (uint8_t)width;
+            hdr[13] = (uint8_t)(width >> 8);
+            hdr[14] = (uint8_t)height;
+            hdr[15] = (uint8_t)(height >> 8);
+            hdr[16] = 24;
+            hdr[17] = 0x20;
+            if (width > 65535 || height > 65535) throw std::runtime_error("image too large for TGA: " + p);
+            f.write((const char *)hdr, 18);
+            std::vector<uint8_t> line((size_t)width * 3);
+            for (uint32_t y = 0; y < height; ++y) {
+                const uint8_t *src = rgb + (size_t)y * width * 3;
+                for (uint32_t x = 0; x < width; ++x) {
+                    line[3 * x] = src[3 * x + 2];
+                    line[3 * x + 1] = src[3 * x + 1];
+                    line[3 * x + 2] = src[3 * x];
+                }
+                f.write((const char *)line.data(), (std::streamsize)line.size());
+            }
+        } else if (ppm) {
             f << "P6\n" << width << " " << height << "\n255\n";
             f.write((const char *)rgb, (std::streamsize)((size_t)width * height * 3));
         } else {  // 24-bit BMP, bottom-up rows, BGR, rows padded to 4 bytes

@@ -357,6 +357,23 @@ def test_malformed_jpegs_are_errors_not_crashes(tmp_path):
     assert decoded > 20                        # damage in the scan data usually still decodes (to a damaged image)
 
 
+def test_written_images_round_trip(tmp_path):
+    """The output format follows the file name (src/main.rs:70-72 saves through the `image` crate, which does the same):
+    PNG, BMP, PPM and TGA files written here read back pixel for pixel; a format the writer lacks is an error."""
+    from PIL import Image
+    from v4ray_hip import write_image
+    rng = np.random.default_rng(5)
+    for shape in ((37, 53, 3), (1, 1, 3), (300, 301, 3)):   # 300 x 301 x 3 + filter bytes: more than one stored deflate block
+        img = rng.integers(0, 256, size=shape, dtype=np.uint8)
+        for ext in ("png", "bmp", "ppm", "tga", "PNG"):
+            path = tmp_path / f"a.{ext}"
+            write_image(path, img)
+            back = np.asarray(Image.open(path).convert("RGB"))
+            assert np.array_equal(back, img), (shape, ext)
+    with pytest.raises(V4RayError, match="not supported"):
+        write_image(tmp_path / "a.jpg", img)
+
+
 # ---- RenderResult, renderer.rs:336-406 ----------------------------------------------------------------
 def test_render_result_tonemap_table():
     res = RenderResult(4, 1)
