@@ -377,17 +377,17 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
                         // at this level and the deeper ones of the batch (walls would otherwise serialise the chip on a
                         // handful of addresses -- every launch anew, until each compute unit has seen the flag; from that
                         // count on the rule treats every packet as full).  The flag is read and written with plain
-                        // accesses: a stale 0 only costs one more increment.  Its load is issued beside the primitive's class.
+                        // accesses: a stale 0 only costs one more increment.  Shapes full in every pass (build()) skip all of it.
+                        const uint32_t info = S.prim_info[best.prim], cls = info >> 24;
                         uint32_t *n_rays = Q.shape_rays;
                         uint32_t full = 1u;
-                        if (count_shape_rays) {
+                        if (count_shape_rays && !(info & PRIM_INFO_ALWAYS_FULL)) {  // (a shape full in every pass is not counted at all)
                             uint32_t pass = PRIMARY ? pass_in_batch : pass_of_slot(slot, npix, A.inv_npix);
                             if (V4R_CHECK(Q.stats + 8, CHECK_RAY_COUNTER, (size_t)(pass + 1u) * S.n_prims <= Q.flags_offset)) {
                                 n_rays += (size_t)pass * S.n_prims + best.prim;
                                 full = n_rays[Q.flags_offset];
                             }
                         }
-                        const uint32_t info = S.prim_info[best.prim], cls = info >> 24;
                         if (info & PRIM_INFO_PLAIN_LIGHT) {
                             // DiffuseLight (material/diffuse_light.rs:19-22) of one colour on an untransformed rectangle: the
                             // path ends here with throughput x emitted; nothing is queued for a shading launch.  The face test
@@ -501,7 +501,9 @@ V4R_DEV bool shade_hit(const SceneDev &S, const Queues &Q, const PathState &p, f
     uint32_t n_rays = 0u;
     if ((CLS == CLS_LAMBERT || CLS == CLS_LAMBERT_NOISE) && S.packet_rule) {
         const uint32_t *counter = Q.shape_rays + (size_t)pass_of_slot(p.slot, Q.npix, Q.inv_npix) * S.n_prims + prim;
-        n_rays = counter[0];  // a counter that filled up at a shallower level was left standing (k_restart_counters)
+        // a shape known to fill up in every pass is not counted; a counter that filled up at a shallower level was left
+        // standing (k_restart_counters)
+        n_rays = (rec1.w & SHADE_ALWAYS_FULL) ? V4R_PACKET_MANY_RAYS : counter[0];
     }
     if (CLS == CLS_LIGHT) {  // material/diffuse_light.rs:19-22; scatter() is the default None
         HitD h = reconstruct(S, prim, p.o, p.d, t, dcol.z, dcol.w, false);
@@ -985,7 +987,7 @@ int validate(const v4r_scene_desc *d, uint32_t &depth_out) {
     if (int rc = need(d->images, d->n_images, "images")) return rc;
     if (int rc = need(d->perlin, d->n_perlin, "perlin")) return rc;
     if (int rc = need(d->lights, d->n_lights, "lights")) return rc;
-    if (d->n_materials > 0x7FFFFu) return set_error(V4R_E_LIMIT, "too many materials");
+    if (d->n_materials > 0x3FFFFu) return set_error(V4R_E_LIMIT, "too many materials");
 
     // BVH: n-1 interior nodes for n >= 2 primitives, every primitive reachable exactly once.
     if (d->n_prims <= 1) {
@@ -1549,16 +1551,15 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
         if (textured && has_noise(d, mat.tex)) r->class_noise[cls] = true;
     }
     if (int rc = r->upload(&S.prim_info, info.data(), info.size())) return rc;
-    {
-        std::vector<uint4> shade((size_t)d->n_prims * 2);
-        for (uint32_t i = 0; i < d->n_prims; ++i) {
-            const v4r_material &mat = d->materials[d->prim_material[i]];
-            bool textured = mat.kind == V4R_MAT_LAMBERTIAN || mat.kind == V4R_MAT_DIFFUSE_LIGHT || mat.kind == V4R_MAT_ISOTROPIC;
-            static_assert(sizeof(v4r_material) == 32 && sizeof(v4r_texture) == 32, "shade records are 32 bytes");
-            std::memcpy(&shade[2 * (size_t)i], textured ? (const void *)&d->textures[mat.tex] : (const void *)&mat, 32);
-        }
-        if (int rc = r->upload(&S.prim_shade, shade.data(), shade.size())) return rc;
+    std::vector<uint4> shade((size_t)d->n_prims * 2);
+    for (uint32_t i = 0; i < d->n_prims; ++i) {
+        const v4r_material &mat = d->materials[d->prim_material[i]];
+        bool textured = mat.kind == V4R_MAT_LAMBERTIAN || mat.kind == V4R_MAT_DIFFUSE_LIGHT || mat.kind == V4R_MAT_ISOTROPIC;
+        static_assert(sizeof(v4r_material) == 32 && sizeof(v4r_texture) == 32, "shade records are 32 bytes");
+        std::memcpy(&shade[2 * (size_t)i], textured ? (const void *)&d->textures[mat.tex] : (const void *)&mat, 32);
+        shade[2 * (size_t)i + 1].w = 0u;  // the records' padding word: SHADE_ALWAYS_FULL, set below
     }
+    if (int rc = r->upload(&S.prim_shade, shade.data(), shade.size())) return rc;
     if (int rc = r->upload(&S.xforms, (const float *)d->xforms, (size_t)d->n_xforms * 24)) return rc;
     if (int rc = r->upload(&S.tri, (const float4 *)d->tri_shading, (size_t)d->n_tri_shading * 4)) return rc;
     if (int rc = r->upload(&S.media, (const uint4 *)d->media, (size_t)d->n_media)) return rc;
@@ -1672,6 +1673,46 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     r->noalloc.stream = r->stream;
     HIP_TRY(hipEventCreateWithFlags(&r->noalloc.done, hipEventDisableTiming));
     carve_noalloc(r, n_cu);
+
+    // Packet-statistics rule: shapes that fill up at the first level of every pass.  The deterministic camera rays (one
+    // through each pixel centre) are traced once; a Lambertian shape that at least 4 x V4R_PACKET_MANY_RAYS of them end on
+    // receives V4R_PACKET_MANY_RAYS jittered camera rays in any pass, so at level 0 -- and, a full shape staying full, at
+    // every deeper level -- it is full without being counted: no flag to read, no counter to contend for (walls, floors).
+    if (S.packet_rule && d->n_prims != 0 && !std::getenv("V4R_NO_ALWAYS_FULL")) {
+        uint32_t *d_prim = nullptr;
+        float *d_t = nullptr;
+        if (int rc = r->alloc(&d_prim, r->npix)) return rc;
+        if (int rc = r->alloc(&d_t, r->npix)) return rc;
+        auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3(r->grid_trace), dim3(BLOCK), 0, r->stream, r->S, r->pipes[0].Q, r->npix, (const float *)nullptr,
+                               (const float *)nullptr, 0u, 0u, d_prim, d_t);
+        };
+        switch (r->media_mode) {
+            case MEDIA_IN_TREE: launch(k_trace_rays<MEDIA_IN_TREE>); break;
+            case MEDIA_DIRECT: launch(k_trace_rays<MEDIA_DIRECT>); break;
+            default: launch(k_trace_rays<MEDIA_NONE>); break;
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(r->stream));
+        std::vector<uint32_t> seen(r->npix);
+        HIP_TRY(hipMemcpy(seen.data(), d_prim, (size_t)r->npix * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        std::vector<uint32_t> pixels(d->n_prims, 0u);
+        for (uint32_t p : seen)
+            if (p < d->n_prims) pixels[p]++;
+        bool any = false;
+        for (uint32_t i = 0; i < d->n_prims; ++i) {
+            const uint32_t cls = info[i] >> 24;
+            if (pixels[i] >= 4u * V4R_PACKET_MANY_RAYS && (cls == CLS_LAMBERT || cls == CLS_LAMBERT_NOISE)) {
+                info[i] |= PRIM_INFO_ALWAYS_FULL;
+                shade[2 * (size_t)i + 1].w = SHADE_ALWAYS_FULL;
+                any = true;
+            }
+        }
+        if (any) {
+            HIP_TRY(hipMemcpy(const_cast<uint32_t *>(S.prim_info), info.data(), info.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(const_cast<uint4 *>(S.prim_shade), shade.data(), shade.size() * sizeof(uint4), hipMemcpyHostToDevice));
+        }
+    }
 
     if (int rc = r->alloc(&r->accum_own, (size_t)r->npix * 3)) return rc;
     HIP_TRY(hipMemset(r->accum_own, 0, (size_t)r->npix * 3 * sizeof(float)));

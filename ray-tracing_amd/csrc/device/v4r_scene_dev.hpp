@@ -20,7 +20,9 @@ enum {
 };
 
 constexpr uint32_t NO_PRIM = 0xFFFFFFFFu;
-// prim_info word: material index (19 bits) | flags | shading class << 24
+// prim_info word: material index (18 bits) | flags | shading class << 24
+constexpr uint32_t PRIM_INFO_ALWAYS_FULL = 1u << 18;  // a Lambertian shape that so many camera rays end on that it is "full" (packet rule) in every pass
+constexpr uint32_t SHADE_ALWAYS_FULL = 1u;            // the same, in the padding word of the shape's prim_shade record
 constexpr uint32_t PRIM_INFO_SMALL = 1u << 19;        // the shape is too small to expect more than a few rays of a pass (k_trace's ray counters)
 constexpr uint32_t PRIM_INFO_PLAIN_LIGHT = 1u << 23;  // one-colour DiffuseLight on an untransformed rectangle: k_trace ends the path itself
 constexpr uint32_t PRIM_INFO_POSITIVE = 1u << 22;     // ... whose outward normal points along +axis
