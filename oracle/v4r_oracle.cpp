@@ -1491,6 +1491,30 @@ int v4o_light_value(const v4r_scene_desc *s, uint32_t prim_index, const float or
     *out = light_value(ctx, prim_index, v3(origin), v3(dir));
     return V4R_OK;
 }
+// HittableGroup::value over the scene's lights under the packet-statistics rule, for a ray whose shape `n` rays of its pass
+// and level ended on, `li` = the light index it drew, `seg_key` = the key of its segment's random stream.
+int v4o_lights_value_stat(const v4r_scene_desc *s, const float origin[3], const float normal[3], const float dir[3], uint32_t li, uint32_t n,
+                          uint32_t seg_key, float *out) {
+    if (int rc = validate(s)) return rc;
+    if (s->n_lights == 0 || li >= s->n_lights) {
+        g_error = "no such light";
+        return V4R_E_INVALID;
+    }
+    Ctx ctx{s};
+    *out = lights_value_stat(ctx, v3(origin), v3(normal), v3(dir), li, n, seg_key);
+    return V4R_OK;
+}
+// The share of cosine-distributed directions from surface point p (normal n) that the rule takes to hit light primitive
+// `prim_index` (light_cosine_share).
+int v4o_light_cosine_share(const v4r_scene_desc *s, uint32_t prim_index, const float p[3], const float n[3], float *out) {
+    if (int rc = validate(s)) return rc;
+    if (prim_index >= s->n_prims) {
+        g_error = "primitive index out of range";
+        return V4R_E_INVALID;
+    }
+    *out = light_cosine_share(s->prims[prim_index], v3(p), v3(n));
+    return V4R_OK;
+}
 int v4o_light_generate(const v4r_scene_desc *s, uint32_t prim_index, const float origin[3], float u0, float u1, float out[3]) {
     if (int rc = validate(s)) return rc;
     Ctx ctx{s};

@@ -49,6 +49,8 @@ def lib():
     L.v4o_onb.restype = None
     L.v4o_light_value.argtypes = [D, u32, FP, FP, FP]
     L.v4o_light_generate.argtypes = [D, u32, FP, f32, f32, FP]
+    L.v4o_lights_value_stat.argtypes = [D, FP, FP, FP, u32, u32, u32, FP]
+    L.v4o_light_cosine_share.argtypes = [D, u32, FP, FP, FP]
     L.v4o_reflect.argtypes = [FP, FP, FP]
     L.v4o_reflect.restype = None
     L.v4o_refract.argtypes = [FP, FP, f32, FP]
@@ -159,6 +161,19 @@ def onb(normal):
 def light_value(desc, prim_index, origin, direction):
     out = C.c_float()
     _check(lib().v4o_light_value(desc, prim_index, _f(origin)[1], _f(direction)[1], C.byref(out)))
+    return float(out.value)
+
+
+def lights_value_stat(desc, origin, normal, direction, li, n, seg_key):
+    """The light list's pdf value under the packet-statistics rule (see v4o_lights_value_stat)."""
+    out = C.c_float()
+    _check(lib().v4o_lights_value_stat(desc, _f(origin)[1], _f(normal)[1], _f(direction)[1], li, n, seg_key, C.byref(out)))
+    return float(out.value)
+
+
+def light_cosine_share(desc, prim_index, p, n):
+    out = C.c_float()
+    _check(lib().v4o_light_cosine_share(desc, prim_index, _f(p)[1], _f(n)[1], C.byref(out)))
     return float(out.value)
 
 

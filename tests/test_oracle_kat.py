@@ -289,6 +289,64 @@ def test_triangle_light_generate_stays_inside_and_pdf():
         assert pdf == pytest.approx(h["t"] ** 2 / (abs(v[1]) * 2.0), rel=1e-4)  # area = 2
 
 
+def test_packet_statistics_rule_of_the_light_pdf():
+    """lights_value_stat, the expectation of the reference's 8-lane packets (aa_rect.rs:158-179, renderer.rs:189-217,
+    mixture.rs:27-32, group.rs:91-95).  One rectangle light, a direction that misses it from a floor point:
+      * a direction that hits gets the plane density whatever the packet;
+      * alone on its shape (n = 1) a miss gets 0 -- the bounded density;
+      * with one mate (n = 2) it gets the plane density when that mate hits the light: probability 1/2 + h/2;
+      * in a full packet (n >= 8 ... full from 256 on) with probability 1 - (1/2 - h/2)^7;
+      * in a shape of 12 rays the ray sits in the partial packet of 4 with probability 4/12;
+    h = the light's cosine-weighted solid angle seen from the point (light_cosine_share), itself checked against its
+    definition by sampling cosine-distributed directions."""
+    light = DiffuseLight(SolidColor((1, 1, 1)))
+    s, d = one(ZXRect(-50, 50, -50, 50, 400.0, False), light, important=True)    # 100 x 100, 400 above the origin
+    origin, normal = np.float32([30, 0, -20]), np.float32([0, 1, 0])
+    h = oracle.light_cosine_share(d, 0, origin, normal)
+    rng = np.random.default_rng(21)
+    hits, n_dirs = 0, 40000
+    for r1, r2 in rng.random((n_dirs, 2)):
+        v = oracle.cosine_generate(normal, float(r1), float(r2))
+        hits += oracle.hit(d, 0, origin, v)["mask"]
+    assert h == pytest.approx(hits / n_dirs, rel=0.1)          # centre / area / normal estimate vs the sampled share
+    assert 0.01 < h < 0.05
+    miss = np.float32([0.6, 0.8, 0.0])
+    toward = oracle.light_generate(d, 0, origin, 0.3, 0.6)
+    plane = oracle.light_value(d, 0, origin, miss)
+    assert plane > 0 and not oracle.hit(d, 0, origin, miss)["mask"]
+    keys = [oracle.lib().v4o_rng_segment_key(77, 0, k, 3) for k in range(4000)]
+    for n in (1, 2, 12, 300):
+        assert all(oracle.lights_value_stat(d, origin, normal, toward, 0, n, k) == pytest.approx(oracle.light_value(d, 0, origin, toward))
+                   for k in keys[:50])
+    got = {n: np.mean([oracle.lights_value_stat(d, origin, normal, miss, 0, n, k) != 0.0 for k in keys]) for n in (1, 2, 8, 12, 300)}
+    vals = {oracle.lights_value_stat(d, origin, normal, miss, 0, 300, k) for k in keys[:200]}
+    assert all(v == 0.0 or abs(v - plane) <= 1e-6 * plane for v in vals) and len(vals) == 2
+    q = 0.5 - 0.5 * h
+    tol = 3 * 0.5 / math.sqrt(len(keys))
+    assert got[1] == 0.0
+    assert got[2] == pytest.approx(1 - q, abs=tol)
+    assert got[8] == pytest.approx(1 - q ** 7, abs=tol) and got[300] == pytest.approx(1 - q ** 7, abs=tol)
+    assert got[12] == pytest.approx((4 / 12) * (1 - q ** 3) + (8 / 12) * (1 - q ** 7), abs=tol)
+    # a second light that the packet did not draw is only reached by the mates' cosine directions
+    s2 = Scene((0, 0, 0))
+    s2.add(ZXRect(-50, 50, -50, 50, 400.0, False), light, True)
+    s2.add(ZXRect(-50, 50, -50, 50, -300.0, True), light, True)     # below the floor point: never hit by its cosine directions
+    s2.add(Sphere((0, 0, 0), 0.5), Lambertian(SolidColor((0.5, 0.5, 0.5))))
+    d2 = s2.flatten(RendererParam(8, 8), PerspectiveCameraParam((0, 0, -5), (0, 0, 0), 40.0))
+    p0, p1 = oracle.light_value(d2, 0, origin, miss), oracle.light_value(d2, 1, origin, miss)
+    assert p0 == pytest.approx(plane) and p1 > 0 and abs(p1 - p0) > 0.1 * p0
+    with0 = with1 = 0
+    for k in keys:                                                  # the packet drew light 1
+        v = oracle.lights_value_stat(d2, origin, normal, miss, 1, 300, k)
+        parts = {(a, b): 0.5 * (a * p0 + b * p1) for a in (0, 1) for b in (0, 1)}
+        a, b = min(parts, key=lambda ab: abs(parts[ab] - v))
+        assert abs(parts[(a, b)] - v) <= 1e-5 * (p0 + p1)
+        with0 += a
+        with1 += b
+    assert with0 / len(keys) == pytest.approx(1 - (1 - 0.5 * h) ** 7, abs=tol)    # light 0: cosine directions of the mates only
+    assert with1 / len(keys) == pytest.approx(1 - 0.5 ** 7, abs=tol)              # light 1: the mates that aimed at it
+
+
 def test_transformed_light_pdf_has_no_jacobian():
     # transform.rs:103-116: value() evaluates the object-space density at the object-space origin/direction
     light = DiffuseLight(SolidColor((1, 1, 1)))
