@@ -267,7 +267,7 @@ struct PrimaryArgs {
 // ranking as the hits); the second launch (SECOND) traces the given-up rays of the whole
 // segment packed next to each other, starting from the closest hit they had found, and never gives up.
 // (SECOND is a template parameter because the extra index it carries costs the first launch an occupancy step.)
-template <bool COUNT, int RAYS_PER_THREAD, int MEDIA, bool PRIMARY, bool SECOND>
+template <bool COUNT, int RAYS_PER_THREAD, int MEDIA, bool PRIMARY, bool SECOND, bool WIDE8>
 __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES_MEDIA : (PRIMARY || MEDIA == MEDIA_DIRECT ? V4R_TRACE_MIN_WAVES_PRIMARY : V4R_TRACE_MIN_WAVES)) void k_trace(SceneDev S, Queues Q, uint32_t seg, PrimaryArgs A, uint32_t give_up_lanes) {
     constexpr bool second = SECOND;
     __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
                     }
                     return segment_key(k0, k1, seg);
                 };
-                bool gave_up = traverse<COUNT, MEDIA>(S, o, d, active, st, best, cnt, key, second ? 0u : give_up_lanes, second);
+                bool gave_up = traverse<COUNT, MEDIA, WIDE8>(S, o, d, active, st, best, cnt, key, second ? 0u : give_up_lanes, second);
                 // what becomes of the ray: the queue it goes to (a shading class, or CLS_COUNT = given up), or none (its path ended)
                 uint32_t dest = DEST_NONE;
                 if (active && gave_up) {
@@ -670,7 +670,7 @@ V4R_DEV void tail_shade(const SceneDev &S, const Queues &Q, uint32_t cls, float4
 #ifndef V4R_TAIL_MIN_WAVES_NOISE
 #define V4R_TAIL_MIN_WAVES_NOISE 3  // the Perlin code alone needs ~150 VGPRs; unforced the kernel has 172-196 (2 waves/SIMD)
 #endif
-template <bool COUNT, int MEDIA, bool NOISE>
+template <bool COUNT, int MEDIA, bool NOISE, bool WIDE8>
 __global__ __launch_bounds__(BLOCK, NOISE ? V4R_TAIL_MIN_WAVES_NOISE : 1) void k_tail(SceneDev S, Queues Q, uint32_t seg0) {
     __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
     __shared__ v4f s_top[8 * TOP_NODES];
@@ -719,7 +719,7 @@ __global__ __launch_bounds__(BLOCK, NOISE ? V4R_TAIL_MIN_WAVES_NOISE : 1) void k
         best.prim = NO_PRIM;
         best.u = best.v = 0.0f;
         auto key = [&]() { return segment_key(p.k0, p.k1, seg); };
-        traverse<COUNT, MEDIA>(S, p.o, p.d, alive, st, best, cnt, key, 0u);
+        traverse<COUNT, MEDIA, WIDE8>(S, p.o, p.d, alive, st, best, cnt, key, 0u);
         if (alive) {
             if (COUNT) n_traced++;
             if (best.prim == NO_PRIM) {  // renderer.rs:184: a miss takes the background colour
@@ -798,7 +798,8 @@ __global__ __launch_bounds__(BLOCK) void k_tonemap(const float *accum, size_t n,
 // Closest hit of explicit rays (or of the deterministic primary rays when origin == nullptr).
 // Ray i draws the free path of a constant medium from the stream of path (seed, pass 0, pixel i);
 // the deterministic primary rays use key 0.
-template <int MEDIA>
+// COUNT: the traversal work is added to Q.stats ([1] node steps, [2] primitive tests, [6] wave steps, [7] wave leaf steps).
+template <int MEDIA, bool WIDE8, bool COUNT = false>
 __global__ __launch_bounds__(BLOCK) void k_trace_rays(SceneDev S, Queues Q, uint32_t n, const float *origin, const float *dir,
                                                       uint32_t seed_lo, uint32_t seed_hi, uint32_t *prim_out, float *t_out) {
     __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
@@ -840,10 +841,19 @@ __global__ __launch_bounds__(BLOCK) void k_trace_rays(SceneDev S, Queues Q, uint
         best.t = V4R_INF;
         best.prim = NO_PRIM;
         best.u = best.v = 0.0f;
-        traverse<false, MEDIA>(S, o, d, valid, st, best, cnt, key, 0u);
+        traverse<COUNT, MEDIA, WIDE8>(S, o, d, valid, st, best, cnt, key, 0u);
         if (valid) {
             prim_out[i] = best.prim;
             t_out[i] = best.t;
+        }
+    }
+    if (COUNT) {
+        unsigned long long n = wave_sum(cnt.nodes), q = wave_sum(cnt.prims);
+        if (lane_id() == 0) {
+            atomicAdd(&Q.stats[1], n);
+            atomicAdd(&Q.stats[2], q);
+            atomicAdd(&Q.stats[6], (unsigned long long)cnt.wave_steps);
+            atomicAdd(&Q.stats[7], (unsigned long long)cnt.wave_leaves);
         }
     }
 }
@@ -913,6 +923,8 @@ struct v4r_renderer {
     int media_mode = MEDIA_NONE;  // selects the kernel instantiations (see traverse)
     bool class_noise[CLS_COUNT] = {false, false, false, false, false, false};  // a material of the class uses a noise texture
     uint32_t give_up_lanes = 0, give_up_segments = 0;  // see k_trace
+    bool wide8 = false;          // the traversed tree is the compressed 8-wide one (wide_step8), else the 4-wide one
+    uint32_t stack_fanout = 3;   // entries a node step can push
     uint32_t tile_passes_log2 = 4;  // passes per wave tile of the camera-ray order (see ray_order)
     size_t ctr_bytes = 0;
     uint32_t max_depth = 0, spill_depth = 0;
@@ -1250,9 +1262,14 @@ void rebuild_binary(const v4r_scene_desc *d, bool without_media, std::vector<v4r
 // by that child's two children.  Leaves stay single primitives, so the set of (ray, primitive) tests
 // that can happen is the one of the binary tree.  Nodes are emitted parent before children, siblings
 // next to each other.
-uint32_t collapse_to_wide(const v4r_scene_desc *d, const v4r_bvh_node *nodes, uint32_t n_nodes, std::vector<float4> &out, uint32_t &n_top) {
+// WIDE = 8: the compressed 8-wide tree of wide_step8, built the same way; `encodable` turns false (and the tree must not be
+// used) when a box is not finite.
+template <int WIDE>
+uint32_t collapse_to_wide(const v4r_scene_desc *d, const v4r_bvh_node *nodes, uint32_t n_nodes, std::vector<float4> &out, uint32_t &n_top,
+                          bool &encodable) {
     out.clear();
     n_top = 0;
+    encodable = true;
     if (n_nodes == 0) return 0;
     // which subtrees of the binary tree hold a constant medium (wide_step must not cull those by distance)
     std::vector<uint8_t> holds_medium(n_nodes, 0);
@@ -1317,12 +1334,12 @@ uint32_t collapse_to_wide(const v4r_scene_desc *d, const v4r_bvh_node *nodes, ui
             todo.pop_back();
         }
         // the children of levels < TOP_LEVELS are numbered (and expanded) breadth first, before anything deeper
-        std::vector<Task> &next = from_top && t.depth < (uint32_t)TOP_LEVELS ? top : todo;
+        std::vector<Task> &next = from_top && t.depth < (uint32_t)(WIDE == 8 ? TOP_LEVELS_8 : TOP_LEVELS) ? top : todo;
         depth = std::max(depth, t.depth);
-        Item items[4];
+        Item items[WIDE];
         int n = 2;
         children(t.binary, items[0], items[1]);
-        while (n < 4) {
+        while (n < WIDE) {
             int pick = -1;
             float best = -1.0f;
             for (int k = 0; k < n; ++k)
@@ -1339,17 +1356,10 @@ uint32_t collapse_to_wide(const v4r_scene_desc *d, const v4r_bvh_node *nodes, ui
             children(node, items[pick], items[n]);
             ++n;
         }
-        float lo[3][4], hi[3][4];
-        uint32_t child[4], mask = 0;
+        uint32_t child[WIDE], mask = 0;
         for (int k = 0; k < n; ++k)
             if (never_cull(items[k].child)) mask |= 1u << k;
-        for (int k = 0; k < 4; ++k) {
-            for (int a = 0; a < 3; ++a) {
-                // NaN planes make every comparison of the slab test false (an inverted box would not: the test
-                // orders the two planes of an axis itself)
-                lo[a][k] = k < n ? items[k].lo[a] : std::numeric_limits<float>::quiet_NaN();
-                hi[a][k] = k < n ? items[k].hi[a] : std::numeric_limits<float>::quiet_NaN();
-            }
+        for (int k = 0; k < WIDE; ++k) {
             if (k >= n) child[k] = 0xFFFFFFFFu;
             else if (items[k].child & V4R_LEAF_BIT) child[k] = items[k].child;
             else {
@@ -1359,6 +1369,15 @@ uint32_t collapse_to_wide(const v4r_scene_desc *d, const v4r_bvh_node *nodes, ui
             }
         }
         float4 *w = out.data() + 8 * (size_t)t.wide;
+        if constexpr (WIDE == 4) {
+        float lo[3][4], hi[3][4];
+        for (int k = 0; k < 4; ++k)
+            for (int a = 0; a < 3; ++a) {
+                // NaN planes make every comparison of the slab test false (an inverted box would not: the test
+                // orders the two planes of an axis itself)
+                lo[a][k] = k < n ? items[k].lo[a] : std::numeric_limits<float>::quiet_NaN();
+                hi[a][k] = k < n ? items[k].hi[a] : std::numeric_limits<float>::quiet_NaN();
+            }
         for (int a = 0; a < 3; ++a) {
             w[a] = make_float4(lo[a][0], lo[a][1], lo[a][2], lo[a][3]);
             w[3 + a] = make_float4(hi[a][0], hi[a][1], hi[a][2], hi[a][3]);
@@ -1369,6 +1388,58 @@ uint32_t collapse_to_wide(const v4r_scene_desc *d, const v4r_bvh_node *nodes, ui
         float mask_bits;
         std::memcpy(&mask_bits, &mask, 4);
         w[7] = make_float4(mask_bits, 0.0f, 0.0f, 0.0f);
+        } else {
+        // Compressed 8-wide node, one 128-byte line: origin p and one power-of-two scale per axis, the children's boxes as
+        // 8-bit offsets from p in units of the scale (lower planes rounded down, upper planes up: the decoded box contains
+        // the child's), eight child words.  A box that is not finite cannot be encoded: work[0] = inf then, and the tree must not be used.
+        float p[3];
+        uint32_t biased[3];
+        uint8_t qlo[3][8], qhi[3][8];
+        for (int k = 0; k < n; ++k)
+            for (int a = 0; a < 3; ++a)
+                if (!std::isfinite(items[k].lo[a]) || !std::isfinite(items[k].hi[a])) encodable = false;  // cannot be put on a grid
+        if (!encodable) continue;  // (the tree is walked to the end, but no longer written)
+        for (int a = 0; a < 3; ++a) {
+            float lo_all = inf, hi_all = -inf;
+            for (int k = 0; k < n; ++k) {
+                lo_all = std::min(lo_all, items[k].lo[a]);
+                hi_all = std::max(hi_all, items[k].hi[a]);
+            }
+            if (!(lo_all <= hi_all)) lo_all = hi_all = 0.0f;
+            p[a] = lo_all;
+            int e = -100;
+            if (hi_all > lo_all) e = std::max(-100, (int)std::ceil(std::log2(((double)hi_all - (double)lo_all) / 255.0)));
+            auto decoded = [&](int q, int ee) { return p[a] + (float)q * std::ldexp(1.0f, ee); };  // as the device computes it
+            while (decoded(255, e) < hi_all) ++e;
+            biased[a] = (uint32_t)(e + 127);
+            const double scale = std::ldexp(1.0, e);
+            for (int k = 0; k < 8; ++k) {
+                qlo[a][k] = 255;
+                qhi[a][k] = 0;
+                if (k >= n) continue;
+                int ql = (int)std::floor(((double)items[k].lo[a] - (double)p[a]) / scale), qh = (int)std::ceil(((double)items[k].hi[a] - (double)p[a]) / scale);
+                ql = std::max(0, std::min(255, ql));
+                qh = std::max(0, std::min(255, qh));
+                while (ql > 0 && decoded(ql, e) > items[k].lo[a]) --ql;
+                while (qh < 255 && decoded(qh, e) < items[k].hi[a]) ++qh;
+                qlo[a][k] = (uint8_t)ql;
+                qhi[a][k] = (uint8_t)qh;
+            }
+        }
+        auto word = [](const uint8_t *b) { return (uint32_t)b[0] | (uint32_t)b[1] << 8 | (uint32_t)b[2] << 16 | (uint32_t)b[3] << 24; };
+        auto f = [](uint32_t u) {
+            float v;
+            std::memcpy(&v, &u, 4);
+            return v;
+        };
+        w[0] = make_float4(p[0], p[1], p[2], f(biased[0] | biased[1] << 8 | biased[2] << 16 | mask << 24));
+        w[1] = make_float4(f(child[0]), f(child[1]), f(child[2]), f(child[3]));
+        w[2] = make_float4(f(child[4]), f(child[5]), f(child[6]), f(child[7]));
+        w[3] = make_float4(f(word(qlo[0])), f(word(qlo[0] + 4)), f(word(qlo[1])), f(word(qlo[1] + 4)));
+        w[4] = make_float4(f(word(qlo[2])), f(word(qlo[2] + 4)), f(word(qhi[0])), f(word(qhi[0] + 4)));
+        w[5] = make_float4(f(word(qhi[1])), f(word(qhi[1] + 4)), f(word(qhi[2])), f(word(qhi[2] + 4)));
+        w[6] = w[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
     }
     n_top = (uint32_t)top.size();  // one task per node of the top levels; they were numbered first
     return depth;  // in wide nodes, root = 1
@@ -1379,6 +1450,9 @@ uint32_t cap_counted_passes(const v4r_renderer *r, uint32_t passes) {
     if (!r->S.packet_rule || r->S.n_prims == 0) return passes;
     return std::max(1u, std::min<uint32_t>(passes, std::max(16u, (32u << 20) / r->S.n_prims)));
 }
+
+// Prices of the tree choice in build(), in node steps of the 4-wide tree per wave: a node step of the 8-wide tree, a leaf step.
+constexpr double WIDE8_STEP_COST = 1.6, WIDE_LEAF_COST = 1.0;
 
 // Give `pipe` queues for at least `need` path slots (and ray counters for `n_passes` passes, see Queues::shape_rays).  Growing frees the old queues first (after the
 // pipeline has drained), so a renderer's footprint follows the largest batch it has been asked for:
@@ -1489,7 +1563,8 @@ void carve_noalloc(v4r_renderer *r, int n_cu) {
 
 int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     (void)bvh_depth;  // the traversal stack is sized by the wide tree made below
-    uint32_t wide_depth = 0;
+    uint32_t wide_depth = 0, wide_depth8 = 0, n_top8 = 0;
+    const float4 *nodes8 = nullptr;  // the 8-wide tree, when the scene has one
     HIP_TRY(hipSetDevice(r->device));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, r->device));
@@ -1511,14 +1586,26 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
             S.n_media_direct = (uint32_t)media_list.size();
         }
         r->media_mode = direct ? MEDIA_DIRECT : (d->n_media != 0 ? MEDIA_IN_TREE : MEDIA_NONE);
+        std::vector<v4r_bvh_node> better;
+        const v4r_bvh_node *binary = d->nodes;
+        uint32_t n_binary = d->n_nodes;
         if (!(d->flags & V4R_FLAG_KEEP_HOST_BVH) && d->n_nodes > 0) {
-            std::vector<v4r_bvh_node> better;
             rebuild_binary(d, direct, better);
-            wide_depth = collapse_to_wide(d, better.data(), (uint32_t)better.size(), wide, S.n_top_nodes);
-        } else {
-            wide_depth = collapse_to_wide(d, d->nodes, d->n_nodes, wide, S.n_top_nodes);
+            binary = better.data();
+            n_binary = (uint32_t)better.size();
         }
+        // Two shapes of the traversed tree: 4-wide with exact child boxes, and 8-wide with the child boxes on an 8-bit grid
+        // (half as many dependent node fetches per ray, each step about 1.6 x the vector work, boxes a little larger).
+        // Both are uploaded; pick_tree() below keeps the one that does less work for this scene's camera rays.
+        std::vector<float4> wide8;
+        bool encodable = true;
+        wide_depth = collapse_to_wide<4>(d, binary, n_binary, wide, S.n_top_nodes, encodable);
         if (int rc = r->upload(&S.nodes4, wide.data(), wide.size())) return rc;
+        if (!(d->flags & V4R_FLAG_KEEP_HOST_BVH) && n_binary > 0) {
+            wide_depth8 = collapse_to_wide<8>(d, binary, n_binary, wide8, n_top8, encodable);
+            if (encodable)
+                if (int rc = r->upload(&nodes8, wide8.data(), wide8.size())) return rc;
+        }
     }
     if (int rc = r->upload(&S.prims, (const float4 *)d->prims, (size_t)d->n_prims * 3)) return rc;
     std::vector<uint32_t> info(d->n_prims);
@@ -1608,8 +1695,63 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     S.max_depth = d->max_depth;
     S.antialias = d->antialias;
 
-    // queues
     r->npix = d->width * d->height;
+    if (int rc = r->alloc(&r->stats, 16)) return rc;
+    HIP_TRY(hipMemset(r->stats, 0, 128));
+    // Which tree: the deterministic camera rays (one through each pixel centre) are traced through both with the work counted;
+    // the 8-wide tree is kept when its node steps, priced at WIDE8_STEP_COST steps of the 4-wide tree, and its extra leaf
+    // steps come to less.  The counts are exact, so the choice is a function of the scene (V4R_WIDE=4|8 forces one).
+    if (nodes8) {
+        const uint32_t grid = (uint32_t)n_cu * 4u;
+        const uint32_t depth_max = std::max(3u * wide_depth, 7u * wide_depth8) + 1u;
+        const size_t spill = depth_max > (uint32_t)LDS_DEPTH ? depth_max - LDS_DEPTH : 0;
+        uint2 *slab = nullptr;
+        uint32_t *d_prim = nullptr;
+        float *d_t = nullptr;
+        HIP_TRY(hipMalloc((void **)&slab, std::max<size_t>(256, spill * grid * BLOCK * sizeof(uint2))));
+        HIP_TRY(hipMalloc((void **)&d_prim, (size_t)r->npix * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **)&d_t, (size_t)r->npix * sizeof(float)));
+        Queues Q{};
+        Q.spill = slab;
+        Q.spill_stride = (size_t)grid * BLOCK;
+        Q.spill_depth = (uint32_t)spill;
+        Q.stats = r->stats;
+        unsigned long long work[2][8];
+        for (int w8 = 0; w8 < 2; ++w8) {
+            SceneDev T = S;
+            if (w8) T.nodes4 = nodes8, T.n_top_nodes = n_top8;
+            auto launch = [&](auto kernel) {
+                hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), 0, r->stream, T, Q, r->npix, (const float *)nullptr, (const float *)nullptr, 0u, 0u,
+                                   d_prim, d_t);
+            };
+            switch (r->media_mode) {
+                case MEDIA_IN_TREE: w8 ? launch(k_trace_rays<MEDIA_IN_TREE, true, true>) : launch(k_trace_rays<MEDIA_IN_TREE, false, true>); break;
+                case MEDIA_DIRECT: w8 ? launch(k_trace_rays<MEDIA_DIRECT, true, true>) : launch(k_trace_rays<MEDIA_DIRECT, false, true>); break;
+                default: w8 ? launch(k_trace_rays<MEDIA_NONE, true, true>) : launch(k_trace_rays<MEDIA_NONE, false, true>); break;
+            }
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(r->stream));
+            HIP_TRY(hipMemcpy(work[w8], r->stats, sizeof work[w8], hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemset(r->stats, 0, 128));
+        }
+        (void)hipFree(slab);
+        (void)hipFree(d_prim);
+        (void)hipFree(d_t);
+        const double cost4 = (double)work[0][6] + WIDE_LEAF_COST * (double)work[0][7], cost8 = WIDE8_STEP_COST * (double)work[1][6] + WIDE_LEAF_COST * (double)work[1][7];
+        r->wide8 = cost8 < cost4;
+        if (const char *env = std::getenv("V4R_WIDE")) r->wide8 = std::atoi(env) == 8;
+        if (std::getenv("V4R_VERBOSE"))
+            std::fprintf(stderr, "v4r: camera rays: 4-wide %llu nodes %llu tests %llu wave steps %llu wave leaves; 8-wide %llu nodes %llu tests %llu wave steps %llu wave leaves -> %d-wide\n",
+                         work[0][1], work[0][2], work[0][6], work[0][7], work[1][1], work[1][2], work[1][6], work[1][7], r->wide8 ? 8 : 4);
+        if (r->wide8) {
+            S.nodes4 = nodes8;
+            S.n_top_nodes = n_top8;
+            wide_depth = wide_depth8;
+        }
+    }
+    r->stack_fanout = r->wide8 ? 7u : 3u;
+
+    // queues
     size_t target = 64u << 20;  // paths per batch
     if (const char *env = std::getenv("V4R_BATCH_PATHS")) {
         long long v = std::atoll(env);
@@ -1630,8 +1772,13 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     };
     r->grid_trace = with_media_mode([&](auto m) {
         constexpr int M = decltype(m)::value;
-        return std::max(std::max(grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, M, false, false>, n_cu), grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, M, true, false>, n_cu)),
-                        grid_for(k_trace_rays<M>, n_cu));
+        if (r->wide8)
+            return std::max(std::max(grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, M, false, false, true>, n_cu),
+                                     grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, M, true, false, true>, n_cu)),
+                            grid_for(k_trace_rays<M, true>, n_cu));
+        return std::max(std::max(grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, M, false, false, false>, n_cu),
+                                 grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, M, true, false, false>, n_cu)),
+                        grid_for(k_trace_rays<M, false>, n_cu));
     });
     r->grid_shade = (uint32_t)n_cu * 8u;
     r->grid_stream = (uint32_t)n_cu * 8u;
@@ -1639,7 +1786,8 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     {
         uint32_t g = with_media_mode([&](auto m) {
             constexpr int M = decltype(m)::value;
-            return r->any_noise ? grid_for(k_tail<false, M, true>, n_cu) : grid_for(k_tail<false, M, false>, n_cu);
+            if (r->wide8) return r->any_noise ? grid_for(k_tail<false, M, true, true>, n_cu) : grid_for(k_tail<false, M, false, true>, n_cu);
+            return r->any_noise ? grid_for(k_tail<false, M, true, false>, n_cu) : grid_for(k_tail<false, M, false, false>, n_cu);
         });
         r->grid_tail = std::min(g, r->grid_trace);  // the stack spill slab has one column per thread of a trace launch
     }
@@ -1650,11 +1798,9 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     // the tail kernel does not count rays per shape: under the packet-statistics rule it starts after the counted levels
     if (S.packet_rule && r->tail_segment != 0) r->tail_segment = std::max(r->tail_segment, V4R_PACKET_COUNTED_LEVELS);
     // a ray's stack holds at most three entries per level of the wide tree above its current node
-    uint32_t stack_max = 3u * wide_depth + 1u;
+    uint32_t stack_max = r->stack_fanout * wide_depth + 1u;  // a step pushes every entered child but the nearest
     uint32_t spill_depth = stack_max > (uint32_t)LDS_DEPTH ? stack_max - LDS_DEPTH : 0;
     r->ctr_bytes = sizeof(SegCtr) * ((size_t)d->max_depth + 1);
-    if (int rc = r->alloc(&r->stats, 16)) return rc;
-    HIP_TRY(hipMemset(r->stats, 0, 128));
     HIP_TRY(hipEventCreateWithFlags(&r->fork, hipEventDisableTiming));
     r->pipes.resize(n_pipes);
     r->max_depth = d->max_depth;
@@ -1688,9 +1834,9 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
                                (const float *)nullptr, 0u, 0u, d_prim, d_t);
         };
         switch (r->media_mode) {
-            case MEDIA_IN_TREE: launch(k_trace_rays<MEDIA_IN_TREE>); break;
-            case MEDIA_DIRECT: launch(k_trace_rays<MEDIA_DIRECT>); break;
-            default: launch(k_trace_rays<MEDIA_NONE>); break;
+            case MEDIA_IN_TREE: r->wide8 ? launch(k_trace_rays<MEDIA_IN_TREE, true>) : launch(k_trace_rays<MEDIA_IN_TREE, false>); break;
+            case MEDIA_DIRECT: r->wide8 ? launch(k_trace_rays<MEDIA_DIRECT, true>) : launch(k_trace_rays<MEDIA_DIRECT, false>); break;
+            default: r->wide8 ? launch(k_trace_rays<MEDIA_NONE, true>) : launch(k_trace_rays<MEDIA_NONE, false>); break;
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(r->stream));
@@ -1729,8 +1875,13 @@ uint32_t launch_trace_as(v4r_renderer *r, Pipe &pipe, uint32_t seg, const Primar
     constexpr int R = TRACE_RAYS_PER_THREAD;
     // the first segments hold nearly all rays: there a wave gives its last few rays up to a second launch
     uint32_t give_up = seg < r->give_up_segments ? r->give_up_lanes : 0u;
-    hipLaunchKernelGGL((k_trace<COUNT, R, MEDIA, PRIMARY, false>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A, give_up);
-    if (give_up) hipLaunchKernelGGL((k_trace<COUNT, R, MEDIA, PRIMARY, true>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A, 0u);
+    if (r->wide8) {
+        hipLaunchKernelGGL((k_trace<COUNT, R, MEDIA, PRIMARY, false, true>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A, give_up);
+        if (give_up) hipLaunchKernelGGL((k_trace<COUNT, R, MEDIA, PRIMARY, true, true>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A, 0u);
+    } else {
+        hipLaunchKernelGGL((k_trace<COUNT, R, MEDIA, PRIMARY, false, false>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A, give_up);
+        if (give_up) hipLaunchKernelGGL((k_trace<COUNT, R, MEDIA, PRIMARY, true, false>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A, 0u);
+    }
     return give_up ? 2u : 1u;
 }
 template <bool COUNT, int MEDIA>
@@ -1770,8 +1921,13 @@ uint32_t launch_shade(v4r_renderer *r, Pipe &pipe, uint32_t seg) {
 template <bool COUNT, int MEDIA>
 void launch_tail_as(v4r_renderer *r, Pipe &pipe, uint32_t seg) {
     dim3 grid(pipe.grid_tail), block(BLOCK);
-    if (r->any_noise) hipLaunchKernelGGL((k_tail<COUNT, MEDIA, true>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg);
-    else hipLaunchKernelGGL((k_tail<COUNT, MEDIA, false>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg);
+    if (r->wide8) {
+        if (r->any_noise) hipLaunchKernelGGL((k_tail<COUNT, MEDIA, true, true>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg);
+        else hipLaunchKernelGGL((k_tail<COUNT, MEDIA, false, true>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg);
+    } else {
+        if (r->any_noise) hipLaunchKernelGGL((k_tail<COUNT, MEDIA, true, false>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg);
+        else hipLaunchKernelGGL((k_tail<COUNT, MEDIA, false, false>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg);
+    }
 }
 template <bool COUNT>
 void launch_tail_counting(v4r_renderer *r, Pipe &pipe, uint32_t seg) {
@@ -2148,9 +2304,9 @@ static int trace_common(v4r_renderer *r, uint32_t n, const float *host_origin, c
                                (uint32_t)(seed >> 32), d_p, d_t);
         };
         switch (r->media_mode) {
-            case MEDIA_IN_TREE: launch(k_trace_rays<MEDIA_IN_TREE>); break;
-            case MEDIA_DIRECT: launch(k_trace_rays<MEDIA_DIRECT>); break;
-            default: launch(k_trace_rays<MEDIA_NONE>); break;
+            case MEDIA_IN_TREE: r->wide8 ? launch(k_trace_rays<MEDIA_IN_TREE, true>) : launch(k_trace_rays<MEDIA_IN_TREE, false>); break;
+            case MEDIA_DIRECT: r->wide8 ? launch(k_trace_rays<MEDIA_DIRECT, true>) : launch(k_trace_rays<MEDIA_DIRECT, false>); break;
+            default: r->wide8 ? launch(k_trace_rays<MEDIA_NONE, true>) : launch(k_trace_rays<MEDIA_NONE, false>); break;
         }
         e = hipGetLastError();
     }

@@ -255,8 +255,10 @@ typedef __attribute__((address_space(3))) uint2 lds_uint2;
 #ifndef V4R_TOP_LEVELS
 #define V4R_TOP_LEVELS 3
 #endif
-constexpr int TOP_LEVELS = V4R_TOP_LEVELS;
+constexpr int TOP_LEVELS = V4R_TOP_LEVELS;  // of the 4-wide tree
 constexpr int TOP_NODES = TOP_LEVELS == 4 ? 85 : (TOP_LEVELS == 3 ? 21 : (TOP_LEVELS == 2 ? 5 : 1));
+constexpr int TOP_LEVELS_8 = 2;             // of the 8-wide tree: 1 + 8 nodes, which fit the same LDS array
+static_assert(TOP_NODES >= 9 || TOP_LEVELS < 3, "the LDS copy of the tree top is sized for the 4-wide tree");
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4f lds_v4f;
 constexpr uint32_t TRAV_NONE_WORD = 0xFFFFFFFFu;  // "no entry" (see Wide)
@@ -362,6 +364,76 @@ V4R_DEV void wide_pop(Stack &st, float best_t, Wide &W) {
 // along the whole line (constant_medium.rs:44-84), which may be in front of its box entry, even behind the
 // origin.  Children whose subtree holds a medium (bit k of the node's eighth float4) are therefore never
 // culled by distance: they are entered whenever the ray meets their box and carry entry distance -inf.
+// Node step of the compressed 8-wide tree.  A node is one 128-byte line: {p.xyz, biased exponents x|y<<8|z<<16 | never-cull
+// mask << 24}, eight child words, then the children's planes as bytes -- lower x, lower y, lower z, upper x, upper y, upper z,
+// eight each: plane = p + byte * 2^exponent (lower planes were rounded down, upper ones up, so the decoded box contains the
+// child's).  In ray space a plane's distance is (p - o) * inv + byte * (2^exponent * inv): one multiply-add per plane.  `inv`
+// must be finite (see traverse).  Entered children are sorted near to far by keys `entry bits & ~7 | slot`.
+template <bool COUNT, bool MEDIA>
+V4R_DEV void wide_step8(const SceneDev &S, V3 o, V3 inv, Stack &st, const Best &best, Wide &W, TraceCounters &cnt) {
+    float4 head, kid_lo, kid_hi, qa, qb, qc;
+    if (W.cur < st.n_top) {
+        const lds_v4f *tp = st.top + 8u * W.cur;
+        auto ld = [&](int k) {
+            v4f v = tp[k];
+            return make_float4(v.x, v.y, v.z, v.w);
+        };
+        head = ld(0), kid_lo = ld(1), kid_hi = ld(2), qa = ld(3), qb = ld(4), qc = ld(5);
+    } else {
+        const float4 *np = S.nodes4 + 8 * (size_t)W.cur;
+        head = np[0], kid_lo = np[1], kid_hi = np[2], qa = np[3], qb = np[4], qc = np[5];
+    }
+    if (COUNT) cnt.nodes++;
+    const uint32_t bits = __float_as_uint(head.w);
+    const uint32_t never_cull = MEDIA ? bits >> 24 & 255u : 0u;  // children that hold a medium: entered when their box is met, at any distance
+    const float ax = (head.x - o.x) * inv.x, ay = (head.y - o.y) * inv.y, az = (head.z - o.z) * inv.z;
+    const float bx = __uint_as_float((bits & 255u) << 23) * inv.x, by = __uint_as_float((bits >> 8 & 255u) << 23) * inv.y,
+                bz = __uint_as_float((bits >> 16 & 255u) << 23) * inv.z;
+    uint32_t key[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        // byte c of the eight that the two words (w0: children 0-3, w1: 4-7) hold, as a plane distance
+        auto plane = [&](float w0, float w1, float a, float b) {
+            return __fmaf_rn((float)(__float_as_uint(c < 4 ? w0 : w1) >> (8 * (c & 3)) & 255u), b, a);
+        };
+        const float x0 = plane(qa.x, qa.y, ax, bx), x1 = plane(qb.z, qb.w, ax, bx), y0 = plane(qa.z, qa.w, ay, by), y1 = plane(qc.x, qc.y, ay, by),
+                    z0 = plane(qb.x, qb.y, az, bz), z1 = plane(qc.z, qc.w, az, bz);
+        const float entry = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), EPSILON));
+        const float leave = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+        const bool wanted = entry <= best.t || (never_cull >> c & 1u);
+        const float kid = c == 0 ? kid_lo.x : c == 1 ? kid_lo.y : c == 2 ? kid_lo.z : c == 3 ? kid_lo.w : c == 4 ? kid_hi.x : c == 5 ? kid_hi.y : c == 6 ? kid_hi.z : kid_hi.w;
+        key[c] = (entry < leave && wanted && __float_as_uint(kid) != TRAV_NONE_WORD) ? ((__float_as_uint(entry) & ~7u) | (uint32_t)c) : 0xFFFFFFFFu;
+    }
+    // sort the eight keys ascending (Batcher's odd-even merge sort, 19 compare-exchanges); children not entered sort last
+    auto cas = [&](int a, int b) {
+        uint32_t lo = min(key[a], key[b]), hi = max(key[a], key[b]);
+        key[a] = lo;
+        key[b] = hi;
+    };
+    cas(0, 1), cas(2, 3), cas(4, 5), cas(6, 7);
+    cas(0, 2), cas(1, 3), cas(4, 6), cas(5, 7);
+    cas(1, 2), cas(5, 6);
+    cas(0, 4), cas(1, 5), cas(2, 6), cas(3, 7);
+    cas(2, 4), cas(3, 5);
+    cas(1, 2), cas(3, 4), cas(5, 6);
+    auto child_of = [&](uint32_t k) {  // a tree of selects on the slot's three bits (kept out of scratch: no indexed array)
+        const float a0 = (k & 1u) ? kid_lo.y : kid_lo.x, a1 = (k & 1u) ? kid_lo.w : kid_lo.z, a2 = (k & 1u) ? kid_hi.y : kid_hi.x,
+                    a3 = (k & 1u) ? kid_hi.w : kid_hi.z;
+        const float b0 = (k & 2u) ? a1 : a0, b1 = (k & 2u) ? a3 : a2;
+        return __float_as_uint((k & 4u) ? b1 : b0);
+    };
+    auto entry_of = [&](uint32_t k) { return (never_cull >> (k & 7u) & 1u) ? -V4R_INF : __uint_as_float(k & ~7u); };
+    // farther children first, so that the nearest of them is popped first
+#pragma unroll
+    for (int j = 7; j >= 1; --j)
+        if (key[j] != 0xFFFFFFFFu) st.push(child_of(key[j]), entry_of(key[j]));
+    if (key[0] != 0xFFFFFFFFu) {
+        W.cur = child_of(key[0]);
+        W.cur_entry = entry_of(key[0]);
+    } else {
+        wide_pop(st, best.t, W);
+    }
+}
 template <bool COUNT, bool MEDIA>
 V4R_DEV void wide_step(const SceneDev &S, V3 o, V3 inv, Stack &st, const Best &best, Wide &W, TraceCounters &cnt) {
     float4 lx, ly, lz, hx, hy, hz, kids;
@@ -452,7 +524,7 @@ V4R_DEV void wide_leaves(const SceneDev &S, V3 o, V3 d, Stack &st, Best &best, W
 // MEDIA: how the scene's constant media are met -- MEDIA_NONE: the scene has none; MEDIA_IN_TREE: they are leaves of
 // the tree (wide_step / consider carry the medium code and the never-cull rule); MEDIA_DIRECT: see below.
 enum : int { MEDIA_NONE = 0, MEDIA_IN_TREE = 1, MEDIA_DIRECT = 2 };
-template <bool COUNT, int MEDIA, class KeyFn>
+template <bool COUNT, int MEDIA, bool WIDE8, class KeyFn>
 V4R_DEV bool traverse(const SceneDev &S, V3 o, V3 d, bool active, Stack &st, Best &best, TraceCounters &cnt, KeyFn key,
                       uint32_t give_up_lanes, bool resumed = false) {
     if (S.n_prims == 0) return false;
@@ -474,6 +546,9 @@ V4R_DEV bool traverse(const SceneDev &S, V3 o, V3 d, bool active, Stack &st, Bes
         return false;
     }
     V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    // the compressed node step adds byte * (scale * inv) to (p - o) * inv: both must stay finite.  A ray (anti)parallel to an
+    // axis gets a huge finite reciprocal instead of an infinite one: its plane distances are +-huge with the right signs.
+    if (WIDE8) inv = v3(fminf(fmaxf(inv.x, -1e18f), 1e18f), fminf(fmaxf(inv.y, -1e18f), 1e18f), fminf(fmaxf(inv.z, -1e18f), 1e18f));
     Wide W;
     W.clear();
     if (active) W.start();
@@ -488,7 +563,10 @@ V4R_DEV bool traverse(const SceneDev &S, V3 o, V3 d, bool active, Stack &st, Bes
             if (m_parked != 0ull && __popcll(m_parked) * V4R_VOTE_DEN >= (__popcll(m_parked) + __popcll(m_step)) * V4R_VOTE_NUM) break;
             if (COUNT) cnt.wave_steps++;
             ++steps;
-            if (W.stepping()) wide_step<COUNT, MEDIA == MEDIA_IN_TREE>(S, o, inv, st, best, W, cnt);
+            if (W.stepping()) {
+                if (WIDE8) wide_step8<COUNT, MEDIA == MEDIA_IN_TREE>(S, o, inv, st, best, W, cnt);
+                else wide_step<COUNT, MEDIA == MEDIA_IN_TREE>(S, o, inv, st, best, W, cnt);
+            }
         }
         if (__ballot(W.parked()) != 0ull) wide_leaves<COUNT, MEDIA == MEDIA_IN_TREE>(S, o, d, st, best, W, cnt, key);
         if (__ballot(W.cur != TRAV_NONE) == 0ull) break;

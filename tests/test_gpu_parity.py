@@ -466,6 +466,28 @@ def test_second_trace_launch_changes_nothing(name, monkeypatch):
         r2.close()
 
 
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c4", "c5"])
+def test_both_tree_shapes_give_the_same_image(name, monkeypatch):
+    """The renderer keeps whichever of its two trees (4-wide with exact boxes, 8-wide with boxes on an 8-bit grid) does
+    less work for the scene's camera rays.  The closest hit does not depend on the tree, so with either one forced the
+    primary hits are the oracle's and the image is bit-identical; the 8-wide tree takes fewer node steps."""
+    out = {}
+    for width in ("4", "8"):
+        monkeypatch.setenv("V4R_WIDE", width)
+        scene, r = make(name)
+        check_primary(r)
+        r.enable_stats(True)
+        r.render_passes(3)
+        out[width] = (r.read_accumulator()[0], r.read_stats())
+        r.close()
+    assert np.array_equal(out["4"][0], out["8"][0])
+    for field in ("segments", "paths", "shaded"):
+        assert out["4"][1][field] == out["8"][1][field], field
+    assert out["8"][1]["nodes"] != out["4"][1]["nodes"]
+    if name in ("c3", "c4"):
+        assert out["8"][1]["nodes"] < 0.7 * out["4"][1]["nodes"]
+
+
 @pytest.mark.parametrize("name,flags", [("c1", _abi.V4R_FLAG_PLANE_LIGHT_PDF), ("c2", 0), ("c5", _abi.V4R_FLAG_PLANE_LIGHT_PDF), ("c5", 0)])
 def test_tail_kernel_changes_nothing(name, flags, monkeypatch):
     """From some segment on, one launch follows each remaining path to its end instead of one trace launch and
