@@ -274,7 +274,7 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
     __shared__ uint32_t s_base;
     __shared__ uint32_t s_cnt[CLS_COUNT + 1];  // [CLS_COUNT]: rays given up
     __shared__ uint32_t s_where[RAYS_PER_THREAD * BLOCK];  // per ray of the chunk: class << 16 | rank among the chunk's hits of that class
-    __shared__ v4f s_top[8 * TOP_NODES];
+    __shared__ v4f s_top[8 * (WIDE8 ? TOP_NODES_8 : TOP_NODES)];
     Stack st;
     stage_tree_top(S, s_top, st);  // the chunk loop below synchronises before the first traversal
     st.lds = (lds_uint2 *)lds_stack + threadIdx.x;
@@ -673,7 +673,7 @@ V4R_DEV void tail_shade(const SceneDev &S, const Queues &Q, uint32_t cls, float4
 template <bool COUNT, int MEDIA, bool NOISE, bool WIDE8>
 __global__ __launch_bounds__(BLOCK, NOISE ? V4R_TAIL_MIN_WAVES_NOISE : 1) void k_tail(SceneDev S, Queues Q, uint32_t seg0) {
     __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
-    __shared__ v4f s_top[8 * TOP_NODES];
+    __shared__ v4f s_top[8 * (WIDE8 ? TOP_NODES_8 : TOP_NODES)];
     Stack st;
     stage_tree_top(S, s_top, st);
     __syncthreads();
@@ -803,7 +803,7 @@ template <int MEDIA, bool WIDE8, bool COUNT = false>
 __global__ __launch_bounds__(BLOCK) void k_trace_rays(SceneDev S, Queues Q, uint32_t n, const float *origin, const float *dir,
                                                       uint32_t seed_lo, uint32_t seed_hi, uint32_t *prim_out, float *t_out) {
     __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
-    __shared__ v4f s_top[8 * TOP_NODES];
+    __shared__ v4f s_top[8 * (WIDE8 ? TOP_NODES_8 : TOP_NODES)];
     Stack st;
     stage_tree_top(S, s_top, st);
     __syncthreads();

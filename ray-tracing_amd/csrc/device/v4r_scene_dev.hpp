@@ -257,8 +257,11 @@ typedef __attribute__((address_space(3))) uint2 lds_uint2;
 #endif
 constexpr int TOP_LEVELS = V4R_TOP_LEVELS;  // of the 4-wide tree
 constexpr int TOP_NODES = TOP_LEVELS == 4 ? 85 : (TOP_LEVELS == 3 ? 21 : (TOP_LEVELS == 2 ? 5 : 1));
-constexpr int TOP_LEVELS_8 = 2;             // of the 8-wide tree: 1 + 8 nodes, which fit the same LDS array
-static_assert(TOP_NODES >= 9 || TOP_LEVELS < 3, "the LDS copy of the tree top is sized for the 4-wide tree");
+#ifndef V4R_TOP_LEVELS_8
+#define V4R_TOP_LEVELS_8 2
+#endif
+constexpr int TOP_LEVELS_8 = V4R_TOP_LEVELS_8;  // of the 8-wide tree
+constexpr int TOP_NODES_8 = TOP_LEVELS_8 == 3 ? 73 : (TOP_LEVELS_8 == 2 ? 9 : 1);
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4f lds_v4f;
 constexpr uint32_t TRAV_NONE_WORD = 0xFFFFFFFFu;  // "no entry" (see Wide)
