@@ -12,9 +12,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CHECKED = os.path.join(os.path.dirname(HERE), "ray-tracing_amd", "lib", "libv4ray_hip_checked.so")
 
 
-def test_no_bounds_check_fails():
+@pytest.mark.parametrize("tree", ["chosen", "4", "8"])
+def test_no_bounds_check_fails(tree):
+    """With the tree the renderer chooses per scene, and with either shape forced (the 8-wide tree pushes up to seven
+    entries per node step)."""
     assert os.path.exists(CHECKED), "build it with make -C ray-tracing_amd checked"
     env = dict(os.environ, V4R_DEVICE_LIB=CHECKED)
+    if tree != "chosen":
+        env["V4R_WIDE"] = tree
     proc = subprocess.run([sys.executable, os.path.join(HERE, "checked_build_child.py")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                           text=True, timeout=280)
     assert proc.returncode == 0, proc.stdout[-3000:]
