@@ -188,10 +188,14 @@ def random_scene(seed, n_shapes):
     return scene
 
 
-@pytest.mark.parametrize("seed,n_shapes", [(1, 3), (2, 40), (3, 400), (4, 2000)])
-def test_random_scenes_match_oracle(seed, n_shapes):
+@pytest.mark.parametrize("seed,n_shapes,tree", [(1, 3, None), (2, 40, None), (3, 400, None), (4, 2000, None),
+                                                (2, 40, "8"), (3, 400, "8"), (4, 2000, "8"), (3, 400, "4")])
+def test_random_scenes_match_oracle(seed, n_shapes, tree, monkeypatch):
     """Random mixed scenes (every primitive kind, transforms, media) against the oracle: random rays through the
-    scene's box, and a few rendered passes."""
+    scene's box, and a few rendered passes.  With the tree the renderer chooses, and with a shape forced (overlapping
+    media in an 8-wide tree exercise its never-cull mask)."""
+    if tree:
+        monkeypatch.setenv("V4R_WIDE", tree)
     scene = random_scene(seed, n_shapes)
     r = Renderer(RendererParam(96, 64, max_depth=12), PerspectiveCameraParam((0, 0, -30), (0, 0, 0), 50.0), scene)
     rng = np.random.default_rng(100 + seed)
