@@ -598,6 +598,7 @@ class Renderer:
         self.seed = int(seed)
         self._next_pass = 0
         self._lock = threading.Lock()  # render() may run on several executor threads at once (main.py:1986-1990)
+        self._pending, self._pending_lock, self._draining = [], threading.Lock(), False  # render() calls waiting for a batch
         self._desc = scene.flatten(param, camera)
         lib = device_lib()
         h = C.c_void_p()
@@ -632,8 +633,60 @@ class Renderer:
             return self.read_accumulator()[0]
 
     async def render(self) -> np.ndarray:
+        """One pass, awaited (PyRenderer.render, src/renderer.rs:462-476).  Calls in flight at the same time (main.py:1986-1990
+        keeps os.cpu_count() of them going) are served by one batch: n waiting callers -> n consecutive passes rendered in one
+        device job and read back once, and each caller gets that batch's mean pass (one shared read-only array when n > 1).
+        Summed over the callers this is the sum of n distinct passes, which is all the reference's callers do with the
+        results (RenderResult.add, renderer.rs:379-386); a lone caller gets its own single pass, as before."""
         loop = asyncio.get_running_loop()
-        return await loop.run_in_executor(None, self.render_pass)
+        fut = loop.create_future()
+        with self._pending_lock:
+            self._pending.append((loop, fut))
+            start = not self._draining
+            self._draining = True
+        if start:
+            loop.run_in_executor(None, self._drain)
+        return await fut
+
+    def _drain(self) -> None:
+        """Executor thread: serve the waiting render() calls, one batch per round, until none is left."""
+        def deliver(fut, img, err):
+            if fut.done():  # cancelled meanwhile
+                return
+            if err is None:
+                fut.set_result(img)
+            else:
+                fut.set_exception(err)
+
+        while True:
+            with self._pending_lock:
+                batch, self._pending = self._pending, []
+                if not batch:
+                    self._draining = False
+                    return
+            img, err = None, None
+            try:
+                img = self._render_mean(len(batch))
+            except Exception as e:  # handed to every waiter of the batch
+                err = e
+            for loop, fut in batch:
+                try:
+                    loop.call_soon_threadsafe(deliver, fut, img, err)
+                except RuntimeError:  # that caller's loop has closed
+                    pass
+
+    def _render_mean(self, n: int) -> np.ndarray:
+        lib = device_lib()
+        with self._lock:
+            first = self._next_pass
+            self._next_pass += n
+            check_dev(lib.v4r_accum_clear(self._h))
+            check_dev(lib.v4r_render(self._h, self.seed, int(first), 1, int(n)))
+            img = self.read_accumulator()[0]
+        if n > 1:
+            img *= np.float32(1.0 / n)
+            img.setflags(write=False)
+        return img
 
     # -- device-resident accumulation --
     def render_passes(self, n_passes: int, first_pass: int = 0, pass_stride: int = 1, seed: Optional[int] = None,

@@ -599,22 +599,48 @@ def test_media_tested_before_the_tree_change_nothing():
 
 
 def test_concurrent_render_calls_take_turns():
-    """Renderer::render is re-entrant in the reference (main.rs:46-63, main.py:1986-1990 run several at once): eight
-    `await renderer.render()` in flight on one handle return eight different whole passes, the ones single calls return."""
-    import asyncio
+    """Renderer::render is re-entrant in the reference (main.rs:46-63): eight `render_pass()` calls on eight threads
+    return eight different whole passes, the ones single calls return."""
+    from concurrent.futures import ThreadPoolExecutor
     scene, r = make("c3")
     singles = [r.render_pass(k) for k in range(8)]
-
-    async def many():
-        return await asyncio.gather(*[r.render() for _ in range(8)])
     r._next_pass = 0
-    got = asyncio.run(many())
+    with ThreadPoolExecutor(8) as pool:
+        got = list(pool.map(lambda _: r.render_pass(), range(8)))
     used = set()
     for img in got:
         match = [k for k in range(8) if k not in used and np.array_equal(img, singles[k])]
-        assert match, "a concurrent render() returned something that is no single pass"
+        assert match, "a concurrent render_pass() returned something that is no single pass"
         used.add(match[0])
     assert len(used) == 8
+    r.close()
+
+
+def test_awaited_render_calls_share_batches():
+    """`await renderer.render()` (main.py:1986-1990 keeps os.cpu_count() in flight): calls waiting at the same time are
+    served by one batch and get its mean pass, so their sum is the sum of as many distinct passes; a lone call gets
+    exactly the single pass."""
+    import asyncio
+    scene, r = make("c3")
+    singles = [r.render_pass(k) for k in range(12)]
+
+    async def many(n):
+        return await asyncio.gather(*[r.render() for _ in range(n)])
+    r._next_pass = 0
+    got = asyncio.run(many(8))
+    assert r._next_pass == 8 and len(got) == 8
+    want = np.sum(singles[:8], axis=0, dtype=np.float64)
+    have = np.sum(got, axis=0, dtype=np.float64)
+    assert np.allclose(have, want, rtol=1e-5, atol=1e-5)
+    lone = asyncio.run(many(1))[0]
+    assert np.array_equal(lone, singles[8]) and lone.flags.writeable
+    # three rounds of three, as a GUI loop would issue them: still every pass exactly once
+    r._next_pass = 0
+    total = np.zeros_like(want)
+    for _ in range(4):
+        total += np.sum(asyncio.run(many(3)), axis=0, dtype=np.float64)
+    assert r._next_pass == 12
+    assert np.allclose(total, np.sum(singles, axis=0, dtype=np.float64), rtol=1e-5, atol=1e-5)
     r.close()
 
 
