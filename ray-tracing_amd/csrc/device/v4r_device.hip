@@ -1411,6 +1411,7 @@ uint32_t collapse_to_wide(const v4r_scene_desc *d, const v4r_bvh_node *nodes, ui
             if (hi_all > lo_all) e = std::max(-100, (int)std::ceil(std::log2(((double)hi_all - (double)lo_all) / 255.0)));
             auto decoded = [&](int q, int ee) { return p[a] + (float)q * std::ldexp(1.0f, ee); };  // as the device computes it
             while (decoded(255, e) < hi_all) ++e;
+            if (e > 24) encodable = false;  // 255 x 2^e x the largest reciprocal traverse() uses (1e18) must stay finite
             biased[a] = (uint32_t)(e + 127);
             const double scale = std::ldexp(1.0, e);
             for (int k = 0; k < 8; ++k) {

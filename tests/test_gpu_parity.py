@@ -492,6 +492,31 @@ def test_both_tree_shapes_give_the_same_image(name, monkeypatch):
         assert out["8"][1]["nodes"] < 0.7 * out["4"][1]["nodes"]
 
 
+def test_scene_too_large_for_the_8_bit_grid_keeps_the_4_wide_tree(monkeypatch):
+    """The 8-wide tree's plane distances are byte x 2^e x 1/d: beyond e = 24 (boxes wider than about 4e9) they could
+    overflow for an axis-parallel ray, so such a scene has no 8-wide tree and forcing it changes nothing."""
+    scene = Scene((0.5, 0.7, 1.0))
+    scene.add(Sphere((0, -1e10, 0), 1e10), Lambertian(SolidColor((0.5, 0.5, 0.5))))
+    rng = np.random.default_rng(3)
+    for _ in range(60):
+        c = rng.uniform(-8, 8, 3)
+        scene.add(Sphere((float(c[0]), 0.4, float(c[2])), 0.4), Lambertian(SolidColor(tuple(float(x) for x in rng.random(3)))))
+    cam = PerspectiveCameraParam((0, 2, -14), (0, 0.4, 0), 40.0)
+    out = {}
+    for width in ("4", "8"):
+        monkeypatch.setenv("V4R_WIDE", width)
+        r = Renderer(RendererParam(96, 64, max_depth=8), cam, scene)
+        prim_d, t_d = r.trace_primary()
+        prim_o, t_o = oracle.trace_primary(r.desc)
+        assert (prim_d == prim_o).mean() >= 0.999
+        r.enable_stats(True)
+        r.render_passes(2)
+        out[width] = (r.read_accumulator()[0], r.read_stats())
+        r.close()
+    assert np.array_equal(out["4"][0], out["8"][0])
+    assert out["4"][1]["nodes"] == out["8"][1]["nodes"]
+
+
 @pytest.mark.parametrize("name,flags", [("c1", _abi.V4R_FLAG_PLANE_LIGHT_PDF), ("c2", 0), ("c5", _abi.V4R_FLAG_PLANE_LIGHT_PDF), ("c5", 0)])
 def test_tail_kernel_changes_nothing(name, flags, monkeypatch):
     """From some segment on, one launch follows each remaining path to its end instead of one trace launch and
