@@ -514,7 +514,9 @@ def test_scene_too_large_for_the_8_bit_grid_keeps_the_4_wide_tree(monkeypatch):
         out[width] = (r.read_accumulator()[0], r.read_stats())
         r.close()
     assert np.array_equal(out["4"][0], out["8"][0])
-    assert out["4"][1]["nodes"] == out["8"][1]["nodes"]
+    # (which rays a wave hands to the second launch depends on the order chunks were taken in: counts differ by a fraction
+    # of a percent from run to run; the 8-wide tree would take a third fewer node steps)
+    assert abs(out["4"][1]["nodes"] - out["8"][1]["nodes"]) <= 0.01 * out["4"][1]["nodes"]
 
 
 @pytest.mark.parametrize("name,flags", [("c1", _abi.V4R_FLAG_PLANE_LIGHT_PDF), ("c2", 0), ("c5", _abi.V4R_FLAG_PLANE_LIGHT_PDF), ("c5", 0)])
