@@ -257,7 +257,7 @@ int v4r_render_rows(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_
  * device image (every GPU the library runs on holds it until the process ends), and the call makes no hipMalloc,
  * hipFree or other allocating call, creates no event or stream, and launches on the renderer's public stream
  * only.  Limit: one pass (width x height paths) must fit the path slots the scratch has left after the scene's
- * stack-spill slab and segment counters -- about 300 000 for a shallow tree, about 200 000 for the 79 488-triangle
+ * stack-spill slab and segment counters -- about 300 000 for a shallow tree, about 100 000 for the 79 488-triangle
  * bunny; larger images, and scenes whose tree is too deep, get V4R_E_LIMIT with the numbers in v4r_last_error().
  * Passes run in batches of scratch_slots / (width x height).  The scratch is shared by every renderer on the same
  * GPU and keeps the previous call's contents (the call clears the counters it needs at zero): calls that overlap
