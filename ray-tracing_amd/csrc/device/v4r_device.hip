@@ -924,7 +924,6 @@ struct v4r_renderer {
     bool class_noise[CLS_COUNT] = {false, false, false, false, false, false};  // a material of the class uses a noise texture
     uint32_t give_up_lanes = 0, give_up_segments = 0;  // see k_trace
     bool wide8 = false;          // the traversed tree is the compressed 8-wide one (wide_step8), else the 4-wide one
-    uint32_t stack_fanout = 3;   // entries a node step can push
     uint32_t tile_passes_log2 = 4;  // passes per wave tile of the camera-ray order (see ray_order)
     size_t ctr_bytes = 0;
     uint32_t max_depth = 0, spill_depth = 0;
@@ -1262,6 +1261,7 @@ void rebuild_binary(const v4r_scene_desc *d, bool without_media, std::vector<v4r
 // by that child's two children.  Leaves stay single primitives, so the set of (ray, primitive) tests
 // that can happen is the one of the binary tree.  Nodes are emitted parent before children, siblings
 // next to each other.
+// Returns the largest number of entries a traversal of the tree can have on its stack.
 // WIDE = 8: the compressed 8-wide tree of wide_step8, built the same way; `encodable` turns false (and the tree must not be
 // used) when a box is not finite.
 template <int WIDE>
@@ -1322,6 +1322,7 @@ uint32_t collapse_to_wide(const v4r_scene_desc *d, const v4r_bvh_node *nodes, ui
     std::vector<Task> top{{0u, 0u, 1u}};  // breadth first: taken from the front, all before `todo`
     size_t top_next = 0;
     uint32_t depth = 0;
+    std::vector<uint32_t> parent_of(1, 0u), fanout(1, 0u);  // per wide node (children are numbered after their parent)
     out.resize(8);
     const float inf = std::numeric_limits<float>::infinity();
     while (top_next < top.size() || !todo.empty()) {
@@ -1378,8 +1379,12 @@ uint32_t collapse_to_wide(const v4r_scene_desc *d, const v4r_bvh_node *nodes, ui
                 child[k] = (uint32_t)(out.size() / 8);
                 out.resize(out.size() + 8);
                 next.push_back({items[k].child, child[k], t.depth + 1u});
+                parent_of.resize(out.size() / 8, 0u);
+                parent_of[child[k]] = t.wide;
             }
         }
+        fanout.resize(out.size() / 8, 0u);
+        fanout[t.wide] = (uint32_t)n;
         float4 *w = out.data() + 8 * (size_t)t.wide;
         if constexpr (WIDE == 4) {
         float lo[3][4], hi[3][4];
@@ -1455,7 +1460,15 @@ uint32_t collapse_to_wide(const v4r_scene_desc *d, const v4r_bvh_node *nodes, ui
         }
     }
     n_top = (uint32_t)top.size();  // one task per node of the top levels; they were numbered first
-    return depth;  // in wide nodes, root = 1
+    // The deepest the traversal stack can get: a node step pushes every entered child but the nearest, so below node v the
+    // stack holds at most (children of v - 1) + the most any of v's children can add.
+    (void)depth;
+    std::vector<uint32_t> below(fanout.size(), 0u);
+    for (size_t v = fanout.size(); v-- > 0;) {
+        below[v] += fanout[v] - 1u;
+        if (v != 0) below[parent_of[v]] = std::max(below[parent_of[v]], below[v]);
+    }
+    return below[0];
 }
 
 // Under the packet-statistics rule a batch keeps one ray counter per pass and primitive: bound that table to 128 MiB.
@@ -1576,7 +1589,7 @@ void carve_noalloc(v4r_renderer *r, int n_cu) {
 
 int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     (void)bvh_depth;  // the traversal stack is sized by the wide tree made below
-    uint32_t wide_depth = 0, wide_depth8 = 0, n_top8 = 0;
+    uint32_t wide_depth = 0, wide_depth8 = 0, n_top8 = 0;  // deepest traversal stack of either tree
     const float4 *nodes8 = nullptr;  // the 8-wide tree, when the scene has one
     HIP_TRY(hipSetDevice(r->device));
     hipDeviceProp_t prop;
@@ -1716,7 +1729,7 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     // steps come to less.  The counts are exact, so the choice is a function of the scene (V4R_WIDE=4|8 forces one).
     if (nodes8) {
         const uint32_t grid = (uint32_t)n_cu * 4u;
-        const uint32_t depth_max = std::max(3u * wide_depth, 7u * wide_depth8) + 1u;
+        const uint32_t depth_max = std::max(wide_depth, wide_depth8) + 1u;
         const size_t spill = depth_max > (uint32_t)LDS_DEPTH ? depth_max - LDS_DEPTH : 0;
         uint2 *slab = nullptr;
         uint32_t *d_prim = nullptr;
@@ -1762,7 +1775,6 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
             wide_depth = wide_depth8;
         }
     }
-    r->stack_fanout = r->wide8 ? 7u : 3u;
 
     // queues
     // Paths per batch.  A launch ends with the few waves that hold its longest rays, a stretch whose length does not depend on
@@ -1814,8 +1826,8 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     if (const char *env = std::getenv("V4R_TAIL_SEGMENT")) r->tail_segment = (uint32_t)std::max(0, std::atoi(env));
     // the tail kernel does not count rays per shape: under the packet-statistics rule it starts after the counted levels
     if (S.packet_rule && r->tail_segment != 0) r->tail_segment = std::max(r->tail_segment, V4R_PACKET_COUNTED_LEVELS);
-    // a ray's stack holds at most three entries per level of the wide tree above its current node
-    uint32_t stack_max = r->stack_fanout * wide_depth + 1u;  // a step pushes every entered child but the nearest
+    // the traversal stack: LDS_DEPTH entries per thread in LDS, the rest of the tree's worst case in a slab in memory
+    uint32_t stack_max = wide_depth + 1u;
     uint32_t spill_depth = stack_max > (uint32_t)LDS_DEPTH ? stack_max - LDS_DEPTH : 0;
     r->ctr_bytes = sizeof(SegCtr) * ((size_t)d->max_depth + 1);
     HIP_TRY(hipEventCreateWithFlags(&r->fork, hipEventDisableTiming));
