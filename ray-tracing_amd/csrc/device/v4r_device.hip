@@ -246,7 +246,7 @@ V4R_DEV void stage_tree_top(const SceneDev &S, v4f *s_top, Stack &st) {
 // scenes and 46 % on the bunny scene, but its extra votes and low-occupancy set-up code made all but
 // the bunny scene 5-20 % slower, so rays are assigned statically.)
 #ifndef V4R_TRACE_MIN_WAVES
-#define V4R_TRACE_MIN_WAVES 5  // 94-98 VGPRs unforced; tuning hook: forcing 6 waves/SIMD (80 VGPRs) spills and is not faster
+#define V4R_TRACE_MIN_WAVES 5  // 94-98 VGPRs unforced; 6 waves/SIMD (80 VGPRs, 40-70 B of scratch) only pay for large scenes: TREE_8_WIDE_DENSE
 #endif
 #ifndef V4R_TRACE_MIN_WAVES_PRIMARY
 #define V4R_TRACE_MIN_WAVES_PRIMARY 5  // 109-113 VGPRs unforced (4 waves/SIMD); at 96 with 32-40 B of scratch: C4 +1-2 %, others flat
@@ -267,9 +267,15 @@ struct PrimaryArgs {
 // ranking as the hits); the second launch (SECOND) traces the given-up rays of the whole
 // segment packed next to each other, starting from the closest hit they had found, and never gives up.
 // (SECOND is a template parameter because the extra index it carries costs the first launch an occupancy step.)
-template <bool COUNT, int RAYS_PER_THREAD, int MEDIA, bool PRIMARY, bool SECOND, bool WIDE8>
-__global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES_MEDIA : (PRIMARY || MEDIA == MEDIA_DIRECT ? V4R_TRACE_MIN_WAVES_PRIMARY : V4R_TRACE_MIN_WAVES)) void k_trace(SceneDev S, Queues Q, uint32_t seg, PrimaryArgs A, uint32_t give_up_lanes) {
+// TREE: which tree the scene keeps (TREE_4_WIDE, TREE_8_WIDE), or TREE_8_WIDE_DENSE: the 8-wide tree with the launches of
+// the later segments held to 80 VGPRs (6 waves/SIMD; six workgroups' LDS fit a CU with the 8-wide tree's short top).  Scenes
+// whose nodes and primitives overflow the caches spend their time waiting for them, and the sixth wave covers more of that
+// than its 40-70 B of scratch cost: the 1080p bunny scene +3.5 %; small scenes lose (Cornell box -7 %, spheres -2.5 %).
+enum : int { TREE_4_WIDE = 0, TREE_8_WIDE = 1, TREE_8_WIDE_DENSE = 2 };
+template <bool COUNT, int RAYS_PER_THREAD, int MEDIA, bool PRIMARY, bool SECOND, int TREE>
+__global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES_MEDIA : (PRIMARY || MEDIA == MEDIA_DIRECT ? V4R_TRACE_MIN_WAVES_PRIMARY : (TREE == TREE_8_WIDE_DENSE ? 6 : V4R_TRACE_MIN_WAVES))) void k_trace(SceneDev S, Queues Q, uint32_t seg, PrimaryArgs A, uint32_t give_up_lanes) {
     constexpr bool second = SECOND;
+    constexpr bool WIDE8 = TREE != TREE_4_WIDE;
     __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
     __shared__ uint32_t s_base;
     __shared__ uint32_t s_cnt[CLS_COUNT + 1];  // [CLS_COUNT]: rays given up
@@ -924,6 +930,7 @@ struct v4r_renderer {
     bool class_noise[CLS_COUNT] = {false, false, false, false, false, false};  // a material of the class uses a noise texture
     uint32_t give_up_lanes = 0, give_up_segments = 0;  // see k_trace
     bool wide8 = false;          // the traversed tree is the compressed 8-wide one (wide_step8), else the 4-wide one
+    bool dense = false;          // the later segments' trace launches run 6 waves/SIMD (TREE_8_WIDE_DENSE)
     uint32_t tile_passes_log2 = 4;  // passes per wave tile of the camera-ray order (see ray_order)
     size_t ctr_bytes = 0;
     uint32_t max_depth = 0, spill_depth = 0;
@@ -1479,6 +1486,7 @@ uint32_t cap_counted_passes(const v4r_renderer *r, uint32_t passes) {
 
 // Prices of the tree choice in build(), in node steps of the 4-wide tree per wave: a node step of the 8-wide tree, a leaf step.
 constexpr double WIDE8_STEP_COST = 1.6, WIDE_LEAF_COST = 1.0;
+constexpr size_t DENSE_TABLE_BYTES = 1u << 20;  // nodes + primitives from which the trace launches run six waves per SIMD
 
 // Give `pipe` queues for at least `need` path slots (and ray counters for `n_passes` passes, see Queues::shape_rays).  Growing frees the old queues first (after the
 // pipeline has drained), so a renderer's footprint follows the largest batch it has been asked for:
@@ -1589,7 +1597,7 @@ void carve_noalloc(v4r_renderer *r, int n_cu) {
 
 int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     (void)bvh_depth;  // the traversal stack is sized by the wide tree made below
-    uint32_t wide_depth = 0, wide_depth8 = 0, n_top8 = 0;  // deepest traversal stack of either tree
+    uint32_t wide_depth = 0, wide_depth8 = 0, n_top8 = 0, n_nodes8 = 0;  // deepest traversal stack of either tree
     const float4 *nodes8 = nullptr;  // the 8-wide tree, when the scene has one
     HIP_TRY(hipSetDevice(r->device));
     hipDeviceProp_t prop;
@@ -1629,8 +1637,10 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
         if (int rc = r->upload(&S.nodes4, wide.data(), wide.size())) return rc;
         if (!(d->flags & V4R_FLAG_KEEP_HOST_BVH) && n_binary > 0) {
             wide_depth8 = collapse_to_wide<8>(d, binary, n_binary, wide8, n_top8, encodable);
-            if (encodable)
+            if (encodable) {
                 if (int rc = r->upload(&nodes8, wide8.data(), wide8.size())) return rc;
+                n_nodes8 = (uint32_t)(wide8.size() / 8);
+            }
         }
     }
     if (int rc = r->upload(&S.prims, (const float4 *)d->prims, (size_t)d->n_prims * 3)) return rc;
@@ -1773,6 +1783,9 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
             S.nodes4 = nodes8;
             S.n_top_nodes = n_top8;
             wide_depth = wide_depth8;
+            // scenes whose tree and primitives are well beyond the 32 KB vector caches: see TREE_8_WIDE_DENSE
+            r->dense = r->media_mode == MEDIA_NONE && (size_t)n_nodes8 * 128u + (size_t)d->n_prims * 48u > DENSE_TABLE_BYTES;
+            if (const char *env = std::getenv("V4R_TRACE_WAVES")) r->dense = r->media_mode == MEDIA_NONE && std::atoi(env) == 6;
         }
     }
 
@@ -1802,11 +1815,12 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     r->grid_trace = with_media_mode([&](auto m) {
         constexpr int M = decltype(m)::value;
         if (r->wide8)
-            return std::max(std::max(grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, M, false, false, true>, n_cu),
-                                     grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, M, true, false, true>, n_cu)),
+            return std::max(std::max(r->dense && M == MEDIA_NONE ? grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, MEDIA_NONE, false, false, TREE_8_WIDE_DENSE>, n_cu)
+                                                                 : grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, M, false, false, TREE_8_WIDE>, n_cu),
+                                     grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, M, true, false, TREE_8_WIDE>, n_cu)),
                             grid_for(k_trace_rays<M, true>, n_cu));
-        return std::max(std::max(grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, M, false, false, false>, n_cu),
-                                 grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, M, true, false, false>, n_cu)),
+        return std::max(std::max(grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, M, false, false, TREE_4_WIDE>, n_cu),
+                                 grid_for(k_trace<false, TRACE_RAYS_PER_THREAD, M, true, false, TREE_4_WIDE>, n_cu)),
                         grid_for(k_trace_rays<M, false>, n_cu));
     });
     r->grid_shade = (uint32_t)n_cu * 8u;
@@ -1904,13 +1918,14 @@ uint32_t launch_trace_as(v4r_renderer *r, Pipe &pipe, uint32_t seg, const Primar
     constexpr int R = TRACE_RAYS_PER_THREAD;
     // the first segments hold nearly all rays: there a wave gives its last few rays up to a second launch
     uint32_t give_up = seg < r->give_up_segments ? r->give_up_lanes : 0u;
-    if (r->wide8) {
-        hipLaunchKernelGGL((k_trace<COUNT, R, MEDIA, PRIMARY, false, true>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A, give_up);
-        if (give_up) hipLaunchKernelGGL((k_trace<COUNT, R, MEDIA, PRIMARY, true, true>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A, 0u);
-    } else {
-        hipLaunchKernelGGL((k_trace<COUNT, R, MEDIA, PRIMARY, false, false>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A, give_up);
-        if (give_up) hipLaunchKernelGGL((k_trace<COUNT, R, MEDIA, PRIMARY, true, false>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A, 0u);
-    }
+    auto launch = [&](auto tree) {
+        constexpr int TREE = decltype(tree)::value;
+        hipLaunchKernelGGL((k_trace<COUNT, R, MEDIA, PRIMARY, false, TREE>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A, give_up);
+        if (give_up) hipLaunchKernelGGL((k_trace<COUNT, R, MEDIA, PRIMARY, true, TREE>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A, 0u);
+    };
+    if (!r->wide8) launch(std::integral_constant<int, TREE_4_WIDE>{});
+    else if (MEDIA == MEDIA_NONE && !PRIMARY && r->dense) launch(std::integral_constant<int, MEDIA == MEDIA_NONE && !PRIMARY ? TREE_8_WIDE_DENSE : TREE_8_WIDE>{});
+    else launch(std::integral_constant<int, TREE_8_WIDE>{});
     return give_up ? 2u : 1u;
 }
 template <bool COUNT, int MEDIA>

@@ -244,7 +244,7 @@ enum : int { CHECK_STACK_OVERFLOW = 0, CHECK_STACK_UNDERFLOW = 1, CHECK_QUEUE_IN
 // Stack of the traversal: the first LDS_DEPTH entries of each lane live in LDS (conflict-free:
 // entry e of thread t sits at [e][t]); deeper entries spill to a per-thread slab in HBM.
 #ifndef V4R_LDS_DEPTH
-#define V4R_LDS_DEPTH 12
+#define V4R_LDS_DEPTH 10  // (8 to 12 measure the same; 10 lets six workgroups of the 8-wide trace kernel share a CU's LDS)
 #endif
 constexpr int LDS_DEPTH = V4R_LDS_DEPTH;
 // The LDS part is addressed through an LDS-typed pointer: through a generic one the compiler merges
