@@ -492,6 +492,24 @@ def test_both_tree_shapes_give_the_same_image(name, monkeypatch):
         assert out["8"][1]["nodes"] < 0.7 * out["4"][1]["nodes"]
 
 
+def test_six_wave_trace_launches_change_nothing(monkeypatch):
+    """Large scenes on the 8-wide tree run the trace launches of the later segments in an instantiation held to 80
+    registers (six waves per SIMD): same image and counts as the five-wave one."""
+    out = {}
+    for waves in ("5", "6"):
+        monkeypatch.setenv("V4R_WIDE", "8")
+        monkeypatch.setenv("V4R_TRACE_WAVES", waves)
+        monkeypatch.setenv("V4R_GIVE_UP_LANES", "0")   # (which rays go to the second launch depends on scheduling)
+        scene, r = make("c4")
+        r.enable_stats(True)
+        r.render_passes(3)
+        out[waves] = (r.read_accumulator()[0], r.read_stats())
+        r.close()
+    assert np.array_equal(out["5"][0], out["6"][0])
+    for field in ("segments", "paths", "shaded", "nodes", "prims"):
+        assert out["5"][1][field] == out["6"][1][field], field
+
+
 def test_scene_too_large_for_the_8_bit_grid_keeps_the_4_wide_tree(monkeypatch):
     """The 8-wide tree's plane distances are byte x 2^e x 1/d: beyond e = 24 (boxes wider than about 4e9) they could
     overflow for an axis-parallel ray, so such a scene has no 8-wide tree and forcing it changes nothing."""
