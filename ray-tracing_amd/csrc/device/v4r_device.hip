@@ -370,6 +370,9 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
                     return segment_key(k0, k1, seg);
                 };
                 bool gave_up = traverse<COUNT, MEDIA, WIDE8>(S, o, d, active, st, best, cnt, key, second ? 0u : give_up_lanes, second);
+                // (the ray's index as a value the compiler has not seen: the queue addresses below are then computed here, not
+                // before the traversal and carried through it in registers the traversal needs)
+                asm volatile("" : "+v"(i));
                 // what becomes of the ray: the queue it goes to (a shading class, or CLS_COUNT = given up), or none (its path ended)
                 uint32_t dest = DEST_NONE;
                 if (active && gave_up) {
