@@ -251,6 +251,9 @@ V4R_DEV void stage_tree_top(const SceneDev &S, v4f *s_top, Stack &st) {
 #ifndef V4R_TRACE_MIN_WAVES_PRIMARY
 #define V4R_TRACE_MIN_WAVES_PRIMARY 5  // 109-113 VGPRs unforced (4 waves/SIMD); at 96 with 32-40 B of scratch: C4 +1-2 %, others flat
 #endif
+#ifndef V4R_TRACE_MIN_WAVES_DIRECT
+#define V4R_TRACE_MIN_WAVES_DIRECT 5  // scenes with a few media tested before the tree
+#endif
 #ifndef V4R_TRACE_MIN_WAVES_MEDIA
 #define V4R_TRACE_MIN_WAVES_MEDIA 4  // the kernels with the constant-medium code need 133-143 VGPRs unforced (3 waves/SIMD)
 #endif
@@ -273,7 +276,7 @@ struct PrimaryArgs {
 // than its 40-70 B of scratch cost: the 1080p bunny scene +3.5 %; small scenes lose (Cornell box -7 %, spheres -2.5 %).
 enum : int { TREE_4_WIDE = 0, TREE_8_WIDE = 1, TREE_8_WIDE_DENSE = 2 };
 template <bool COUNT, int RAYS_PER_THREAD, int MEDIA, bool PRIMARY, bool SECOND, int TREE>
-__global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES_MEDIA : (PRIMARY || MEDIA == MEDIA_DIRECT ? V4R_TRACE_MIN_WAVES_PRIMARY : (TREE == TREE_8_WIDE_DENSE ? 6 : V4R_TRACE_MIN_WAVES))) void k_trace(SceneDev S, Queues Q, uint32_t seg, PrimaryArgs A, uint32_t give_up_lanes) {
+__global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES_MEDIA : (PRIMARY ? V4R_TRACE_MIN_WAVES_PRIMARY : (MEDIA == MEDIA_DIRECT ? V4R_TRACE_MIN_WAVES_DIRECT : (TREE == TREE_8_WIDE_DENSE ? 6 : V4R_TRACE_MIN_WAVES)))) void k_trace(SceneDev S, Queues Q, uint32_t seg, PrimaryArgs A, uint32_t give_up_lanes) {
     constexpr bool second = SECOND;
     constexpr bool WIDE8 = TREE != TREE_4_WIDE;
     __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
