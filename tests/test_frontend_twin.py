@@ -141,3 +141,58 @@ def test_reference_front_end_builds_its_objects_against_this_package():
         scene.add(shapes[0], m)
     desc = scene.flatten(v4ray_hip.RendererParam(64, 48), camera)
     assert desc.contents.n_prims == 3 and desc.contents.width == 64
+
+
+def _bare_renderer(render_mean):
+    """A Renderer without a device behind it: only the bookkeeping of the awaited render() calls."""
+    import threading
+    r = v4ray_hip.Renderer.__new__(v4ray_hip.Renderer)
+    r._pending, r._pending_lock, r._draining = [], threading.Lock(), False
+    r._render_mean = render_mean
+    r._h = None
+    return r
+
+
+def test_awaited_render_calls_are_served_in_batches():
+    """PyRenderer.render (src/renderer.rs:462-476) as the front end uses it (main.py:1986-1990): calls waiting together are
+    handed to one job; every call gets an answer, and the jobs' sizes add up to the number of calls."""
+    import asyncio
+    import time
+    sizes = []
+
+    def render_mean(n):
+        sizes.append(n)
+        time.sleep(0.01)   # calls made meanwhile wait for the next job
+        return np.full((2, 3, 3), float(n), dtype=np.float32)
+
+    r = _bare_renderer(render_mean)
+
+    async def worker(k, out):
+        for _ in range(5):
+            out.append(await r.render())
+
+    async def run():
+        out = []
+        await asyncio.gather(*[worker(k, out) for k in range(8)])
+        return out
+
+    got = asyncio.run(run())
+    assert len(got) == 40 and sum(sizes) == 40
+    assert max(sizes) > 1            # calls did share jobs
+    assert r._pending == [] and r._draining is False
+
+
+def test_awaited_render_calls_all_see_a_failure():
+    import asyncio
+
+    def render_mean(n):
+        raise v4ray_hip.V4RayError("device lost")
+
+    r = _bare_renderer(render_mean)
+
+    async def run():
+        return await asyncio.gather(*[r.render() for _ in range(4)], return_exceptions=True)
+
+    got = asyncio.run(run())
+    assert len(got) == 4 and all(isinstance(e, v4ray_hip.V4RayError) for e in got)
+    assert r._draining is False
