@@ -392,17 +392,23 @@ V4R_DEV void wide_step8(const SceneDev &S, V3 o, V3 inv, Stack &st, const Best &
     const float ax = (head.x - o.x) * inv.x, ay = (head.y - o.y) * inv.y, az = (head.z - o.z) * inv.z;
     const float bx = __uint_as_float((bits & 255u) << 23) * inv.x, by = __uint_as_float((bits >> 8 & 255u) << 23) * inv.y,
                 bz = __uint_as_float((bits >> 16 & 255u) << 23) * inv.z;
+    // Along an axis the ray meets a box's lower plane first when it travels upwards, its upper plane first otherwise: byte
+    // -> distance is monotonic (one rounding of byte * b + a, lower byte <= upper byte), so the nearer of the two distances
+    // is the one of the plane picked by the sign of the reciprocal -- the same value min / max of the pair would give.
+    // The words that hold the near and the far planes are picked once per node instead of a min and a max per child and axis.
+    const bool sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
+    const float nx0 = sx ? qb.z : qa.x, nx1 = sx ? qb.w : qa.y, fx0 = sx ? qa.x : qb.z, fx1 = sx ? qa.y : qb.w;
+    const float ny0 = sy ? qc.x : qa.z, ny1 = sy ? qc.y : qa.w, fy0 = sy ? qa.z : qc.x, fy1 = sy ? qa.w : qc.y;
+    const float nz0 = sz ? qc.z : qb.x, nz1 = sz ? qc.w : qb.y, fz0 = sz ? qb.x : qc.z, fz1 = sz ? qb.y : qc.w;
     uint32_t key[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         // byte c of the eight that the two words (w0: children 0-3, w1: 4-7) hold, as a plane distance
-        auto plane = [&](float w0, float w1, float a, float b) {
-            return __fmaf_rn((float)(__float_as_uint(c < 4 ? w0 : w1) >> (8 * (c & 3)) & 255u), b, a);
-        };
-        const float x0 = plane(qa.x, qa.y, ax, bx), x1 = plane(qb.z, qb.w, ax, bx), y0 = plane(qa.z, qa.w, ay, by), y1 = plane(qc.x, qc.y, ay, by),
-                    z0 = plane(qb.x, qb.y, az, bz), z1 = plane(qc.z, qc.w, az, bz);
-        const float entry = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), EPSILON));
-        const float leave = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+        auto byte = [&](float w0, float w1) { return (float)(__float_as_uint(c < 4 ? w0 : w1) >> (8 * (c & 3)) & 255u); };
+        // (the near and the far plane of an axis in one v_pk_fma_f32: 22 fewer vector instructions per step, no faster)
+        auto plane = [&](float w0, float w1, float a, float b) { return __fmaf_rn(byte(w0, w1), b, a); };
+        const float entry = fmaxf(fmaxf(plane(nx0, nx1, ax, bx), plane(ny0, ny1, ay, by)), fmaxf(plane(nz0, nz1, az, bz), EPSILON));
+        const float leave = fminf(fminf(plane(fx0, fx1, ax, bx), plane(fy0, fy1, ay, by)), plane(fz0, fz1, az, bz));
         const bool wanted = entry <= best.t || (never_cull >> c & 1u);
         const float kid = c == 0 ? kid_lo.x : c == 1 ? kid_lo.y : c == 2 ? kid_lo.z : c == 3 ? kid_lo.w : c == 4 ? kid_hi.x : c == 5 ? kid_hi.y : c == 6 ? kid_hi.z : kid_hi.w;
         key[c] = (entry < leave && wanted && __float_as_uint(kid) != TRAV_NONE_WORD) ? ((__float_as_uint(entry) & ~7u) | (uint32_t)c) : 0xFFFFFFFFu;
