@@ -1491,7 +1491,9 @@ uint32_t cap_counted_passes(const v4r_renderer *r, uint32_t passes) {
 }
 
 // Prices of the tree choice in build(), in node steps of the 4-wide tree per wave: a node step of the 8-wide tree, a leaf step.
-constexpr double WIDE8_STEP_COST = 1.6, WIDE_LEAF_COST = 1.0;
+// (Measured break-even of the 8-wide step: between 1.15 -- the spheres scene loses 5 % on the 8-wide tree -- and 1.38 -- the
+// 4K textured-spheres scene gains 1 %.)
+constexpr double WIDE8_STEP_COST = 1.35, WIDE_LEAF_COST = 1.0;
 constexpr size_t DENSE_TABLE_BYTES = 1u << 20;  // nodes + primitives from which the trace launches run six waves per SIMD
 
 // Give `pipe` queues for at least `need` path slots (and ray counters for `n_passes` passes, see Queues::shape_rays).  Growing frees the old queues first (after the
