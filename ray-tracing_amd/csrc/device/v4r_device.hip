@@ -248,6 +248,9 @@ V4R_DEV void stage_tree_top(const SceneDev &S, v4f *s_top, Stack &st) {
 #ifndef V4R_TRACE_MIN_WAVES
 #define V4R_TRACE_MIN_WAVES 5  // 94-98 VGPRs unforced; 6 waves/SIMD (80 VGPRs, 40-70 B of scratch) only pay for large scenes: TREE_8_WIDE_DENSE
 #endif
+#ifndef V4R_TRACE_WAVES_DENSE
+#define V4R_TRACE_WAVES_DENSE 6
+#endif
 #ifndef V4R_TRACE_MIN_WAVES_PRIMARY
 #define V4R_TRACE_MIN_WAVES_PRIMARY 5  // 109-113 VGPRs unforced (4 waves/SIMD); at 96 with 32-40 B of scratch: C4 +1-2 %, others flat
 #endif
@@ -271,12 +274,14 @@ struct PrimaryArgs {
 // segment packed next to each other, starting from the closest hit they had found, and never gives up.
 // (SECOND is a template parameter because the extra index it carries costs the first launch an occupancy step.)
 // TREE: which tree the scene keeps (TREE_4_WIDE, TREE_8_WIDE), or TREE_8_WIDE_DENSE: the 8-wide tree with the launches of
-// the later segments held to 80 VGPRs (6 waves/SIMD; six workgroups' LDS fit a CU with the 8-wide tree's short top).  Scenes
-// whose nodes and primitives overflow the caches spend their time waiting for them, and the sixth wave covers more of that
-// than its 40-70 B of scratch cost: the 1080p bunny scene +3.5 %; small scenes lose (Cornell box -7 %, spheres -2.5 %).
+// the later segments held to 80 VGPRs (6 waves/SIMD; six workgroups' LDS fit a CU with the 8-wide tree's short top).  The
+// sixth wave covers more waiting than its 28 B of scratch cost: the 1080p bunny scene +3.8 %, the 4K textured-spheres scene
+// +2 %, the Cornell box +1 %; every scene on the 8-wide tree without media runs it (V4R_TRACE_WAVES=5|6 forces either).
+// (At 40-70 B of scratch, before the node step shrank, only scenes far beyond the caches gained.  Seven waves -- 72 VGPRs,
+// 64 B of scratch, 8-deep LDS stacks -- trace 1.6 % faster on the bunny scene and leave the job's rate where it is.)
 enum : int { TREE_4_WIDE = 0, TREE_8_WIDE = 1, TREE_8_WIDE_DENSE = 2 };
 template <bool COUNT, int RAYS_PER_THREAD, int MEDIA, bool PRIMARY, bool SECOND, int TREE>
-__global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES_MEDIA : (PRIMARY ? V4R_TRACE_MIN_WAVES_PRIMARY : (MEDIA == MEDIA_DIRECT ? V4R_TRACE_MIN_WAVES_DIRECT : (TREE == TREE_8_WIDE_DENSE ? 6 : V4R_TRACE_MIN_WAVES)))) void k_trace(SceneDev S, Queues Q, uint32_t seg, PrimaryArgs A, uint32_t give_up_lanes) {
+__global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES_MEDIA : (PRIMARY ? V4R_TRACE_MIN_WAVES_PRIMARY : (MEDIA == MEDIA_DIRECT ? V4R_TRACE_MIN_WAVES_DIRECT : (TREE == TREE_8_WIDE_DENSE ? V4R_TRACE_WAVES_DENSE : V4R_TRACE_MIN_WAVES)))) void k_trace(SceneDev S, Queues Q, uint32_t seg, PrimaryArgs A, uint32_t give_up_lanes) {
     constexpr bool second = SECOND;
     constexpr bool WIDE8 = TREE != TREE_4_WIDE;
     __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
@@ -1494,7 +1499,6 @@ uint32_t cap_counted_passes(const v4r_renderer *r, uint32_t passes) {
 // (Measured break-even of the 8-wide step: between 1.15 -- the spheres scene loses 5 % on the 8-wide tree -- and 1.38 -- the
 // 4K textured-spheres scene gains 1 %.)
 constexpr double WIDE8_STEP_COST = 1.35, WIDE_LEAF_COST = 1.0;
-constexpr size_t DENSE_TABLE_BYTES = 1u << 20;  // nodes + primitives from which the trace launches run six waves per SIMD
 
 // Give `pipe` queues for at least `need` path slots (and ray counters for `n_passes` passes, see Queues::shape_rays).  Growing frees the old queues first (after the
 // pipeline has drained), so a renderer's footprint follows the largest batch it has been asked for:
@@ -1791,8 +1795,8 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
             S.nodes4 = nodes8;
             S.n_top_nodes = n_top8;
             wide_depth = wide_depth8;
-            // scenes whose tree and primitives are well beyond the 32 KB vector caches: see TREE_8_WIDE_DENSE
-            r->dense = r->media_mode == MEDIA_NONE && (size_t)n_nodes8 * 128u + (size_t)d->n_prims * 48u > DENSE_TABLE_BYTES;
+            // six waves per SIMD for the later segments (TREE_8_WIDE_DENSE): every scene without media
+            r->dense = r->media_mode == MEDIA_NONE;
             if (const char *env = std::getenv("V4R_TRACE_WAVES")) r->dense = r->media_mode == MEDIA_NONE && std::atoi(env) == 6;
         }
     }
