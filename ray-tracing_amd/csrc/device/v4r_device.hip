@@ -225,6 +225,7 @@ V4R_DEV uint32_t class_base(const Queues &Q, uint32_t seg, int cls) {
 
 // Copies the top of the wide tree into the workgroup's LDS array and points the stack at it; the caller
 // synchronises the workgroup before the first traversal.
+template <class Stack>
 V4R_DEV void stage_tree_top(const SceneDev &S, v4f *s_top, Stack &st) {
     for (uint32_t k = threadIdx.x; k < 8u * S.n_top_nodes; k += BLOCK) {
         float4 v = S.nodes4[k];
@@ -246,7 +247,7 @@ V4R_DEV void stage_tree_top(const SceneDev &S, v4f *s_top, Stack &st) {
 // scenes and 46 % on the bunny scene, but its extra votes and low-occupancy set-up code made all but
 // the bunny scene 5-20 % slower, so rays are assigned statically.)
 #ifndef V4R_TRACE_MIN_WAVES
-#define V4R_TRACE_MIN_WAVES 5  // 94-98 VGPRs unforced; 6 waves/SIMD (80 VGPRs, 40-70 B of scratch) only pay for large scenes: TREE_8_WIDE_DENSE
+#define V4R_TRACE_MIN_WAVES 5  // 94-98 VGPRs unforced; the 8-wide tree's later segments run six waves (80 VGPRs, 28 B of scratch): TREE_8_WIDE_DENSE
 #endif
 #ifndef V4R_TRACE_WAVES_DENSE
 #define V4R_TRACE_WAVES_DENSE 6
@@ -284,12 +285,12 @@ template <bool COUNT, int RAYS_PER_THREAD, int MEDIA, bool PRIMARY, bool SECOND,
 __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES_MEDIA : (PRIMARY ? V4R_TRACE_MIN_WAVES_PRIMARY : (MEDIA == MEDIA_DIRECT ? V4R_TRACE_MIN_WAVES_DIRECT : (TREE == TREE_8_WIDE_DENSE ? V4R_TRACE_WAVES_DENSE : V4R_TRACE_MIN_WAVES)))) void k_trace(SceneDev S, Queues Q, uint32_t seg, PrimaryArgs A, uint32_t give_up_lanes) {
     constexpr bool second = SECOND;
     constexpr bool WIDE8 = TREE != TREE_4_WIDE;
-    __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
+    __shared__ uint2 lds_stack[lds_depth(WIDE8) * BLOCK];
     __shared__ uint32_t s_base;
     __shared__ uint32_t s_cnt[CLS_COUNT + 1];  // [CLS_COUNT]: rays given up
     __shared__ uint32_t s_where[RAYS_PER_THREAD * BLOCK];  // per ray of the chunk: class << 16 | rank among the chunk's hits of that class
     __shared__ v4f s_top[8 * (WIDE8 ? TOP_NODES_8 : TOP_NODES)];
-    Stack st;
+    StackT<lds_depth(WIDE8)> st;
     stage_tree_top(S, s_top, st);  // the chunk loop below synchronises before the first traversal
     st.lds = (lds_uint2 *)lds_stack + threadIdx.x;
     st.stride = BLOCK;
@@ -689,9 +690,9 @@ V4R_DEV void tail_shade(const SceneDev &S, const Queues &Q, uint32_t cls, float4
 #endif
 template <bool COUNT, int MEDIA, bool NOISE, bool WIDE8>
 __global__ __launch_bounds__(BLOCK, NOISE ? V4R_TAIL_MIN_WAVES_NOISE : 1) void k_tail(SceneDev S, Queues Q, uint32_t seg0) {
-    __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
+    __shared__ uint2 lds_stack[lds_depth(WIDE8) * BLOCK];
     __shared__ v4f s_top[8 * (WIDE8 ? TOP_NODES_8 : TOP_NODES)];
-    Stack st;
+    StackT<lds_depth(WIDE8)> st;
     stage_tree_top(S, s_top, st);
     __syncthreads();
     st.lds = (lds_uint2 *)lds_stack + threadIdx.x;
@@ -819,9 +820,9 @@ __global__ __launch_bounds__(BLOCK) void k_tonemap(const float *accum, size_t n,
 template <int MEDIA, bool WIDE8, bool COUNT = false>
 __global__ __launch_bounds__(BLOCK) void k_trace_rays(SceneDev S, Queues Q, uint32_t n, const float *origin, const float *dir,
                                                       uint32_t seed_lo, uint32_t seed_hi, uint32_t *prim_out, float *t_out) {
-    __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
+    __shared__ uint2 lds_stack[lds_depth(WIDE8) * BLOCK];
     __shared__ v4f s_top[8 * (WIDE8 ? TOP_NODES_8 : TOP_NODES)];
-    Stack st;
+    StackT<lds_depth(WIDE8)> st;
     stage_tree_top(S, s_top, st);
     __syncthreads();
     st.lds = (lds_uint2 *)lds_stack + threadIdx.x;
@@ -1752,7 +1753,8 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     if (nodes8) {
         const uint32_t grid = (uint32_t)n_cu * 4u;
         const uint32_t depth_max = std::max(wide_depth, wide_depth8) + 1u;
-        const size_t spill = depth_max > (uint32_t)LDS_DEPTH ? depth_max - LDS_DEPTH : 0;
+        constexpr uint32_t in_lds = (uint32_t)std::min(lds_depth(false), lds_depth(true));  // one slab for both trees' runs
+        const size_t spill = depth_max > in_lds ? depth_max - in_lds : 0;
         uint2 *slab = nullptr;
         uint32_t *d_prim = nullptr;
         float *d_t = nullptr;
@@ -1852,9 +1854,10 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     if (const char *env = std::getenv("V4R_TAIL_SEGMENT")) r->tail_segment = (uint32_t)std::max(0, std::atoi(env));
     // the tail kernel does not count rays per shape: under the packet-statistics rule it starts after the counted levels
     if (S.packet_rule && r->tail_segment != 0) r->tail_segment = std::max(r->tail_segment, V4R_PACKET_COUNTED_LEVELS);
-    // the traversal stack: LDS_DEPTH entries per thread in LDS, the rest of the tree's worst case in a slab in memory
+    // the traversal stack: lds_depth(tree) entries per thread in LDS, the rest of the tree's worst case in a slab in memory
     uint32_t stack_max = wide_depth + 1u;
-    uint32_t spill_depth = stack_max > (uint32_t)LDS_DEPTH ? stack_max - LDS_DEPTH : 0;
+    const uint32_t in_lds = (uint32_t)lds_depth(r->wide8);
+    uint32_t spill_depth = stack_max > in_lds ? stack_max - in_lds : 0;
     r->ctr_bytes = sizeof(SegCtr) * ((size_t)d->max_depth + 1);
     HIP_TRY(hipEventCreateWithFlags(&r->fork, hipEventDisableTiming));
     r->pipes.resize(n_pipes);

@@ -241,19 +241,24 @@ enum : int { CHECK_STACK_OVERFLOW = 0, CHECK_STACK_UNDERFLOW = 1, CHECK_QUEUE_IN
 #define V4R_CHECK(errors, code, condition) true
 #endif
 
-// Stack of the traversal: the first LDS_DEPTH entries of each lane live in LDS (conflict-free:
-// entry e of thread t sits at [e][t]); deeper entries spill to a per-thread slab in HBM.
+// Stack of the traversal: the first entries of each lane live in LDS (conflict-free: entry e of thread t sits at
+// [e][t]); deeper entries spill to a per-thread slab in HBM.  The LDS depth goes with the tree the kernel walks, because
+// a CU's LDS is shared with the tree top (below): 10 entries beside the 9-node top of the 8-wide tree (six workgroups
+// per CU), 8 beside the 85-node top of the 4-wide tree (five workgroups).  Depths of 8 to 12 trace equally fast.
 #ifndef V4R_LDS_DEPTH
-#define V4R_LDS_DEPTH 10  // (8 to 12 measure the same; 10 lets six workgroups of the 8-wide trace kernel share a CU's LDS)
+#define V4R_LDS_DEPTH 10
 #endif
-constexpr int LDS_DEPTH = V4R_LDS_DEPTH;
+#ifndef V4R_LDS_DEPTH_4
+#define V4R_LDS_DEPTH_4 8
+#endif
+constexpr int lds_depth(bool wide8) { return wide8 ? V4R_LDS_DEPTH : V4R_LDS_DEPTH_4; }
 // The LDS part is addressed through an LDS-typed pointer: through a generic one the compiler merges
 // the two halves of push/pop into flat loads and stores, which are slower and wait on both counters.
 typedef __attribute__((address_space(3))) uint2 lds_uint2;
 // Top of the tree in LDS (TOP_LEVELS levels, at most TOP_NODES nodes): every ray starts there, and an LDS read has
 // a fraction of the latency of a vector-memory read that hits in L1 and does not occupy the texture addresser.
 #ifndef V4R_TOP_LEVELS
-#define V4R_TOP_LEVELS 3
+#define V4R_TOP_LEVELS 4  // (three levels and 10-deep stacks: the spheres scene traces 2.4 % slower)
 #endif
 constexpr int TOP_LEVELS = V4R_TOP_LEVELS;  // of the 4-wide tree
 constexpr int TOP_NODES = TOP_LEVELS == 4 ? 85 : (TOP_LEVELS == 3 ? 21 : (TOP_LEVELS == 2 ? 5 : 1));
@@ -265,7 +270,9 @@ constexpr int TOP_NODES_8 = TOP_LEVELS_8 == 3 ? 73 : (TOP_LEVELS_8 == 2 ? 9 : 1)
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4f lds_v4f;
 constexpr uint32_t TRAV_NONE_WORD = 0xFFFFFFFFu;  // "no entry" (see Wide)
-struct Stack {
+template <int LDS_DEPTH>
+struct StackT {
+    static constexpr int lds_entries = LDS_DEPTH;
     const lds_v4f *top = nullptr;  // 8 vectors per node, nodes 0 .. n_top-1; n_top = 0: no copy in LDS
     uint32_t n_top = 0;
     lds_uint2 *lds;    // this thread's column: lds[e * block_dim]
@@ -351,6 +358,7 @@ struct Wide {
     }
 };
 
+template <class Stack>
 V4R_DEV void wide_pop(Stack &st, float best_t, Wide &W) {
     W.cur = TRAV_NONE;
     while (st.sp > 0) {
@@ -372,7 +380,7 @@ V4R_DEV void wide_pop(Stack &st, float best_t, Wide &W) {
 // eight each: plane = p + byte * 2^exponent (lower planes were rounded down, upper ones up, so the decoded box contains the
 // child's).  In ray space a plane's distance is (p - o) * inv + byte * (2^exponent * inv): one multiply-add per plane.  `inv`
 // must be finite (see traverse).  Entered children are sorted near to far by keys `entry bits & ~7 | slot`.
-template <bool COUNT, bool MEDIA>
+template <bool COUNT, bool MEDIA, class Stack>
 V4R_DEV void wide_step8(const SceneDev &S, V3 o, V3 inv, Stack &st, const Best &best, Wide &W, TraceCounters &cnt) {
     float4 head, kid_lo, kid_hi, qa, qb, qc;
     if (W.cur < st.n_top) {
@@ -443,7 +451,7 @@ V4R_DEV void wide_step8(const SceneDev &S, V3 o, V3 inv, Stack &st, const Best &
         wide_pop(st, best.t, W);
     }
 }
-template <bool COUNT, bool MEDIA>
+template <bool COUNT, bool MEDIA, class Stack>
 V4R_DEV void wide_step(const SceneDev &S, V3 o, V3 inv, Stack &st, const Best &best, Wide &W, TraceCounters &cnt) {
     float4 lx, ly, lz, hx, hy, hz, kids;
     uint32_t never_cull = 0u;
@@ -511,7 +519,7 @@ V4R_DEV void wide_step(const SceneDev &S, V3 o, V3 inv, Stack &st, const Best &b
 }
 
 // Intersect the parked primitive of every lane of the wave, then pop what each of those lanes does next.
-template <bool COUNT, bool MEDIA, class KeyFn>
+template <bool COUNT, bool MEDIA, class KeyFn, class Stack>
 V4R_DEV void wide_leaves(const SceneDev &S, V3 o, V3 d, Stack &st, Best &best, Wide &W, TraceCounters &cnt, KeyFn key) {
     bool parked = W.parked();
     if (COUNT) cnt.wave_leaves++;
@@ -533,7 +541,7 @@ V4R_DEV void wide_leaves(const SceneDev &S, V3 o, V3 d, Stack &st, Best &best, W
 // MEDIA: how the scene's constant media are met -- MEDIA_NONE: the scene has none; MEDIA_IN_TREE: they are leaves of
 // the tree (wide_step / consider carry the medium code and the never-cull rule); MEDIA_DIRECT: see below.
 enum : int { MEDIA_NONE = 0, MEDIA_IN_TREE = 1, MEDIA_DIRECT = 2 };
-template <bool COUNT, int MEDIA, bool WIDE8, class KeyFn>
+template <bool COUNT, int MEDIA, bool WIDE8, class KeyFn, class Stack>
 V4R_DEV bool traverse(const SceneDev &S, V3 o, V3 d, bool active, Stack &st, Best &best, TraceCounters &cnt, KeyFn key,
                       uint32_t give_up_lanes, bool resumed = false) {
     if (S.n_prims == 0) return false;
