@@ -403,7 +403,9 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
                             uint32_t pass = PRIMARY ? pass_in_batch : pass_of_slot(slot, npix, A.inv_npix);
                             if (V4R_CHECK(Q.stats + 8, CHECK_RAY_COUNTER, (size_t)(pass + 1u) * S.n_prims <= Q.flags_offset)) {
                                 n_rays += (size_t)pass * S.n_prims + best.prim;
-                                full = n_rays[Q.flags_offset];
+                                // (a small shape's flag is never raised -- see below -- so it is not read: one trip to memory less
+                                // at the end of every ray that ends on a mesh triangle)
+                                full = (info & PRIM_INFO_SMALL) ? 0u : n_rays[Q.flags_offset];
                             }
                         }
                         if (info & PRIM_INFO_PLAIN_LIGHT) {
