@@ -346,14 +346,8 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
                 } else {
                     float4 a = rq[0][ii];
                     o = v3(a.x, a.y, a.z);
-                    if (count_shape_rays) {  // the path slot comes with the direction: the ray counter is addressed by its pass
-                        float4 b = rq[1][ii];
-                        d = v3(a.w, b.x, b.y);
-                        slot = __float_as_uint(b.z);
-                    } else {
-                        float2 b = *reinterpret_cast<const float2 *>(&rq[1][ii]);
-                        d = v3(a.w, b.x, b.y);
-                    }
+                    float2 b = *reinterpret_cast<const float2 *>(&rq[1][ii]);
+                    d = v3(a.w, b.x, b.y);
                 }
                 Best best;
                 best.t = V4R_INF;
@@ -400,6 +394,9 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
                         uint32_t *n_rays = Q.shape_rays;
                         uint32_t full = 1u;
                         if (count_shape_rays && !(info & PRIM_INFO_ALWAYS_FULL)) {  // (a shape full in every pass is not counted at all)
+                            // (the path slot, which gives the pass, is read here and not with the direction: a register carried
+                            // through the traversal costs more than this load, which only rays that end on a counted shape make)
+                            if (!PRIMARY) slot = __float_as_uint(rq[1][i].z);
                             uint32_t pass = PRIMARY ? pass_in_batch : pass_of_slot(slot, npix, A.inv_npix);
                             if (V4R_CHECK(Q.stats + 8, CHECK_RAY_COUNTER, (size_t)(pass + 1u) * S.n_prims <= Q.flags_offset)) {
                                 n_rays += (size_t)pass * S.n_prims + best.prim;
