@@ -345,16 +345,16 @@ constexpr uint32_t TRAV_NONE = TRAV_NONE_WORD;
 // empty slot has NaN planes (never entered) and child word TRAV_NONE.
 struct Wide {
     uint32_t cur;      // interior node index, V4R_LEAF_BIT | primitive, or TRAV_NONE when finished / absent
-    float cur_entry;
+    // (The box entry distance of the current entry is not kept: it was compared with the closest hit when the entry was
+    // chosen -- in the node step or in wide_pop -- and a lane's closest hit only moves in its own leaf phase, after which
+    // wide_pop chooses again; so a parked primitive never needs a second look at its distance.)
     __device__ __forceinline__ bool parked() const { return cur != TRAV_NONE && (cur & V4R_LEAF_BIT); }
     __device__ __forceinline__ bool stepping() const { return !(cur & V4R_LEAF_BIT); }
     __device__ __forceinline__ void start() {
         cur = 0u;
-        cur_entry = 0.0f;
     }
     __device__ __forceinline__ void clear() {
         cur = TRAV_NONE;
-        cur_entry = 0.0f;
     }
 };
 
@@ -365,7 +365,6 @@ V4R_DEV void wide_pop(Stack &st, float best_t, Wide &W) {
         uint2 e = st.pop();
         if (__uint_as_float(e.y) <= best_t) {
             W.cur = e.x;
-            W.cur_entry = __uint_as_float(e.y);
             return;
         }
     }
@@ -446,7 +445,6 @@ V4R_DEV void wide_step8(const SceneDev &S, V3 o, V3 inv, Stack &st, const Best &
         if (key[j] != 0xFFFFFFFFu) st.push(child_of(key[j]), entry_of(key[j]));
     if (key[0] != 0xFFFFFFFFu) {
         W.cur = child_of(key[0]);
-        W.cur_entry = entry_of(key[0]);
     } else {
         wide_pop(st, best.t, W);
     }
@@ -512,7 +510,6 @@ V4R_DEV void wide_step(const SceneDev &S, V3 o, V3 inv, Stack &st, const Best &b
     if (key[1] != 0xFFFFFFFFu) st.push(child_of(key[1]), entry_of(key[1]));
     if (key[0] != 0xFFFFFFFFu) {
         W.cur = child_of(key[0]);
-        W.cur_entry = entry_of(key[0]);
     } else {
         wide_pop(st, best.t, W);
     }
@@ -524,10 +521,8 @@ V4R_DEV void wide_leaves(const SceneDev &S, V3 o, V3 d, Stack &st, Best &best, W
     bool parked = W.parked();
     if (COUNT) cnt.wave_leaves++;
     if (parked) {
-        if (W.cur_entry <= best.t) {  // the closest hit may have moved in front of this box since it was stacked
-            if (COUNT) cnt.prims++;
-            consider<MEDIA>(S, W.cur & ~V4R_LEAF_BIT, o, d, best, key);
-        }
+        if (COUNT) cnt.prims++;
+        consider<MEDIA>(S, W.cur & ~V4R_LEAF_BIT, o, d, best, key);
         wide_pop(st, best.t, W);
     }
 }
