@@ -127,7 +127,9 @@ V4R_DEV void camera_ray(const SceneDev &S, uint32_t pixel, uint32_t key, bool de
     }
     const v4r_camera &c = S.cam;
     V3 offset = v3(0, 0, 0);
-    if (!deterministic) {  // random_in_unit_disk, random.rs:18-25
+    // (a pinhole camera -- lens_radius 0, every configured scene but the spheres -- skips the lens sample: its offset is
+    // 0 * u + 0 * v, and origin + (+-0) is the origin)
+    if (!deterministic && c.lens_radius != 0.0f) {  // random_in_unit_disk, random.rs:18-25
         float r = sqrtf(draw(key, DIM_LENS_R));
         float theta = TWO_PI * draw(key, DIM_LENS_THETA);
         float sn, cs;
