@@ -108,10 +108,19 @@ V4R_DEV PathState unpack_ray(float4 a, float4 b, float4 c) {
     return p;
 }
 
+// a / b for a < 2^31 and a quotient below 2^23, without the integer division (some 25 vector instructions): the float
+// quotient with the reciprocal `inv_b` ~ 1 / b is off by at most one, which two comparisons repair.
+V4R_DEV uint32_t div_small(uint32_t a, uint32_t b, float inv_b) {
+    uint32_t q = (uint32_t)((float)a * inv_b);
+    if ((unsigned long long)q * b > a) --q;
+    else if ((unsigned long long)(q + 1u) * b <= a) ++q;
+    return q;
+}
+
 // Renderer::sample (renderer.rs:94-122) + Camera::get_ray (camera.rs:113-129) for one pixel;
 // row 0 is the top of the image (renderer.rs:101 iterates j from height-1 down).
-V4R_DEV void camera_ray(const SceneDev &S, uint32_t pixel, uint32_t key, bool deterministic, V3 &o, V3 &d) {
-    uint32_t row = pixel / S.width, col = pixel - row * S.width;
+V4R_DEV void camera_ray(const SceneDev &S, uint32_t pixel, uint32_t key, bool deterministic, V3 &o, V3 &d, float inv_width = 0.0f) {
+    uint32_t row = inv_width != 0.0f ? div_small(pixel, S.width, inv_width) : pixel / S.width, col = pixel - row * S.width;
     float width = (float)S.width, height = (float)S.height;
     float i = (float)col, j = (float)(S.height - 1u - row);
     float sx, sy;
@@ -158,10 +167,11 @@ struct RayOrder {
     uint32_t tiled_w, tiled_h;  // extent covered by whole tiles
     uint32_t npix_tiled;    // tiled_w * tiled_h
     uint32_t full_groups;   // groups of (1 << lp) passes in this batch
+    float inv_group, inv_tiles_x, inv_width;  // reciprocals of npix << lp, tiles_x and the image width (div_small)
 };
 V4R_DEV void ray_order(const RayOrder &R, uint32_t width, uint32_t npix, uint32_t i, uint32_t &pass, uint32_t &pixel) {
     const uint32_t group = npix << R.lp;
-    uint32_t g = i / group;
+    uint32_t g = div_small(i, group, R.inv_group);
     if (g >= R.full_groups) {
         uint32_t q = i - R.full_groups * group;
         uint32_t b = q / npix;
@@ -174,7 +184,7 @@ V4R_DEV void ray_order(const RayOrder &R, uint32_t width, uint32_t npix, uint32_
         uint32_t tile = r >> 6, w = r & 63u, pix_log = 6u - R.lp;
         uint32_t pw = w & ((1u << pix_log) - 1u);
         pass = (g << R.lp) + (w >> pix_log);
-        uint32_t ty = tile / R.tiles_x, tx = tile - ty * R.tiles_x;
+        uint32_t ty = div_small(tile, R.tiles_x, R.inv_tiles_x), tx = tile - ty * R.tiles_x;
         x = (tx << R.tw_log) + (pw & ((1u << R.tw_log) - 1u));
         y = (ty << R.th_log) + (pw >> R.tw_log);
     } else {
@@ -197,12 +207,7 @@ V4R_DEV void ray_order(const RayOrder &R, uint32_t width, uint32_t npix, uint32_
 
 // slot / npix for a path slot (= pass of the batch * npix + pixel, < 2^31) without the integer division: the float
 // quotient is off by at most one, which two comparisons repair.
-V4R_DEV uint32_t pass_of_slot(uint32_t slot, uint32_t npix, float inv_npix) {
-    uint32_t q = (uint32_t)((float)slot * inv_npix);
-    if ((unsigned long long)q * npix > slot) --q;
-    else if ((unsigned long long)(q + 1u) * npix <= slot) ++q;
-    return q;
-}
+V4R_DEV uint32_t pass_of_slot(uint32_t slot, uint32_t npix, float inv_npix) { return div_small(slot, npix, inv_npix); }
 
 // Rays queued for segment `seg` >= 1: one ray per hit that the scattering classes of the previous
 // segment shaded (lights never scatter, diffuse_light.rs).  Segment 0 traces one camera ray per path slot.
@@ -344,7 +349,7 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
                     ray_order(A.order, S.width, npix, ii, pass_in_batch, pixel);  // pixel: within the band
                     uint32_t k0, k1;
                     path_key(A.seed_lo, A.seed_hi, A.first_pass + pass_in_batch * A.pass_stride, pixel + A.pixel_offset, k0, k1);
-                    camera_ray(S, pixel + A.pixel_offset, segment_key(k0, k1, 0u), false, o, d);
+                    camera_ray(S, pixel + A.pixel_offset, segment_key(k0, k1, 0u), false, o, d, A.order.inv_width);
                 } else {
                     float4 a = rq[0][ii];
                     o = v3(a.x, a.y, a.z);
@@ -2019,6 +2024,9 @@ int run_batch(v4r_renderer *r, Pipe &pipe, uint64_t seed, uint32_t first_pass, u
         order.tiled_h = (n_rows >> order.th_log) << order.th_log;
         order.npix_tiled = order.tiled_w * order.tiled_h;
         order.full_groups = n_batch_passes >> lp;
+        order.inv_group = 1.0f / (float)((unsigned long long)band_pix << lp);
+        order.inv_tiles_x = 1.0f / (float)std::max(1u, order.tiles_x);
+        order.inv_width = 1.0f / (float)r->S.width;
     }
     PrimaryArgs primary{(uint32_t)seed, (uint32_t)(seed >> 32), first_pass, pass_stride, n_paths, band_pix, 1.0f / (float)band_pix, band_offset, order};
     pipe.Q.npix = band_pix;
