@@ -321,7 +321,7 @@ struct StackT {
 #endif
 constexpr uint32_t TRAV_NONE = TRAV_NONE_WORD;
 #ifndef V4R_GIVE_UP_MIN_STEPS
-#define V4R_GIVE_UP_MIN_STEPS 3u  // node steps a wave makes before it may give rays up
+#define V4R_GIVE_UP_MIN_STEPS 2u  // node steps a wave makes before it may give rays up (0 / 1 / 2 / 3: C4 -0.5 / +1 / +2 / 0 %, C3 -1 / +2 / +1.8 / 0 %)
 #endif
 
 // ---- traversal -------------------------------------------------------------------------------------
