@@ -64,6 +64,7 @@ struct Queues {
     float4 *ray[2][3];          // [segment parity][column]: {o.xyz,d.x} {d.yz,slot,thr.r} {thr.gb,k0,k1}
     uint32_t *hit[CLS_COUNT];   // per shading class: the indices (into the ray queue of the segment) of the rays that hit it
     float4 *hitd;               // {t, prim, u, v} of ray i of the segment being traced
+    uint32_t *hitw;             // the primitive word of hitd[i] once more, for k_classify (which then reads 4 instead of 16 bytes per ray)
     uint32_t *given_up;         // indices of the rays whose wave gave them up (see traverse); traced by a second launch
     float4 *rad;                // per path slot: radiance of the finished path
     SegCtr *ctr;                // [max_depth + 1]
@@ -323,7 +324,14 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
     // chunk (down to one), so the launch lasts about one ray's traversal instead of RAYS_PER_THREAD.
     const uint32_t per_thread = min((uint32_t)RAYS_PER_THREAD, max(1u, (n_in + gridDim.x * BLOCK - 1u) / (gridDim.x * BLOCK)));
     const uint32_t chunk = per_thread * BLOCK;
+#ifdef V4R_PHASE_CLOCKS
+    unsigned long long clk_fetch = 0, clk_end = 0, clk_chunk = 0, clk_traverse = 0, wave_rays = 0;
+    const unsigned long long clk_start = COUNT ? phase_clock() : 0ull;
+#endif
     while (true) {
+#ifdef V4R_PHASE_CLOCKS
+        unsigned long long tc = COUNT ? phase_clock() : 0ull;
+#endif
         if (threadIdx.x == 0)
             s_base = started ? gridDim.x * chunk + atomicAdd(second ? &ctr->second_cursor : &ctr->trace_cursor, chunk) : blockIdx.x * chunk;
         if (threadIdx.x <= CLS_COUNT) s_cnt[threadIdx.x] = 0;
@@ -331,10 +339,17 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
         __syncthreads();
         const uint32_t base = s_base;
         if (base >= n_in) break;
+#ifdef V4R_PHASE_CLOCKS
+        if (COUNT) clk_chunk += phase_clock() - tc;
+#endif
 
         {
 #pragma unroll 1
             for (uint32_t j = 0; j < per_thread; ++j) {
+#ifdef V4R_PHASE_CLOCKS
+                const unsigned long long ta = COUNT ? phase_clock() : 0ull;
+                wave_rays++;
+#endif
                 uint32_t pos = base + j * BLOCK + threadIdx.x;
                 bool active = pos < n_in;
                 uint32_t i = active ? pos : n_in - 1u;  // index of the ray in the queue of this segment
@@ -379,7 +394,15 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
                     }
                     return segment_key(k0, k1, seg);
                 };
+#ifdef V4R_PHASE_CLOCKS
+                const unsigned long long tb = COUNT ? phase_clock() : 0ull;
+                if (COUNT) clk_fetch += tb - ta;
+#endif
                 bool gave_up = traverse<COUNT, MEDIA, WIDE8>(S, o, d, active, st, best, cnt, key, second ? 0u : give_up_lanes, second);
+#ifdef V4R_PHASE_CLOCKS
+                const unsigned long long td = COUNT ? phase_clock() : 0ull;
+                if (COUNT) clk_traverse += td - tb;
+#endif
                 // (the ray's index as a value the compiler has not seen: the queue addresses below are then computed here, not
                 // before the traversal and carried through it in registers the traversal needs)
                 asm volatile("" : "+v"(i));
@@ -471,8 +494,14 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
                     todo &= ~same;
                 }
                 s_where[j * BLOCK + threadIdx.x] = w;
+#ifdef V4R_PHASE_CLOCKS
+                if (COUNT) clk_end += phase_clock() - td;
+#endif
             }
         }
+#ifdef V4R_PHASE_CLOCKS
+        tc = COUNT ? phase_clock() : 0ull;
+#endif
         __syncthreads();
         if (threadIdx.x <= CLS_COUNT) {
             uint32_t n = s_cnt[threadIdx.x];
@@ -491,7 +520,23 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
             }
         }
         __syncthreads();
+#ifdef V4R_PHASE_CLOCKS
+        if (COUNT) clk_chunk += phase_clock() - tc;
+#endif
     }
+#ifdef V4R_PHASE_CLOCKS
+    if (COUNT && lane_id() == 0) {  // per kind of launch (camera rays / later segments / second launches): wave cycles by part
+        unsigned long long *out = Q.stats + 16 + 8 * (SECOND ? 2 : (PRIMARY ? 0 : 1));
+        atomicAdd(out + 0, clk_fetch);
+        atomicAdd(out + 1, cnt.clk_node);
+        atomicAdd(out + 2, cnt.clk_leaf);
+        atomicAdd(out + 3, clk_traverse);
+        atomicAdd(out + 4, clk_end);
+        atomicAdd(out + 5, clk_chunk);
+        atomicAdd(out + 6, phase_clock() - clk_start);
+        atomicAdd(out + 7, wave_rays);
+    }
+#endif
     if (COUNT) {
         unsigned long long s = wave_sum(n_traced), n = wave_sum(cnt.nodes), q = wave_sum(cnt.prims), l = wave_sum(n_lights);
         if (lane_id() == 0) {
@@ -502,6 +547,302 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
             atomicAdd(&Q.stats[9], l);
             atomicAdd(&Q.stats[6], (unsigned long long)cnt.wave_steps);
             atomicAdd(&Q.stats[7], (unsigned long long)cnt.wave_leaves);
+        }
+        if (PRIMARY && !SECOND && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&Q.stats[3], (unsigned long long)A.n_paths);
+    }
+}
+
+// ---- the same segment as two kernels: traversal only, then a streaming classification ---------------------------
+// k_trace_only is k_trace without everything that follows a ray's closest hit: it writes the hit record of every ray
+// (misses and given-up rays included) and nothing else -- no primitive-class lookup, no ray counters, no radiance of
+// ended paths, no ranking, no workgroup barrier, no queue.  A wave, not a workgroup, is the unit that takes chunks of
+// the queue.  k_classify then streams over the hit records with every lane busy and does what k_trace did at the end
+// of each ray: end the paths that missed or met a plain light, count rays per shape (packet rule), rank the others
+// within their shading class and append their indices to the class queues (and the given-up rays to theirs).
+#ifndef V4R_TRACE_RUN_MAX
+#define V4R_TRACE_RUN_MAX 4096  // rays a wave takes from the queue at once, at most
+#endif
+constexpr uint32_t HIT_GIVEN_UP = 0x40000000u;        // in the primitive word of a hit record: the wave gave this ray up (primitive indices stay below 2^28)
+constexpr uint32_t HIT_GIVEN_UP_NO_HIT = 0xFFFFFFFEu;  // ... before it had hit anything
+template <bool COUNT, int RAYS_PER_THREAD, int MEDIA, bool PRIMARY, bool SECOND, int TREE>
+__global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES_MEDIA : (PRIMARY ? V4R_TRACE_MIN_WAVES_PRIMARY : (MEDIA == MEDIA_DIRECT ? V4R_TRACE_MIN_WAVES_DIRECT : (TREE == TREE_8_WIDE_DENSE ? V4R_TRACE_WAVES_DENSE : V4R_TRACE_MIN_WAVES)))) void k_trace_only(SceneDev S, Queues Q, uint32_t seg, PrimaryArgs A, uint32_t give_up_lanes) {
+    constexpr bool second = SECOND;
+    constexpr bool WIDE8 = TREE != TREE_4_WIDE;
+    __shared__ uint2 lds_stack[lds_depth(WIDE8) * BLOCK];
+    __shared__ v4f s_top[8 * (WIDE8 ? TOP_NODES_8 : TOP_NODES)];
+    StackT<lds_depth(WIDE8)> st;
+    stage_tree_top(S, s_top, st);
+    __syncthreads();
+    st.lds = (lds_uint2 *)lds_stack + threadIdx.x;
+    st.stride = BLOCK;
+    st.spill = Q.spill + (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    st.spill_stride = Q.spill_stride;
+    st.sp = 0;
+#ifdef V4R_DEBUG_CHECKS
+    st.errors = Q.stats + 8;
+    st.spill_depth = (int)Q.spill_depth;
+#endif
+    SegCtr *ctr = Q.ctr + seg;
+    uint32_t n_in = second ? ctr->given_up : (PRIMARY ? A.n_paths : rays_in(Q, seg));
+    if (!V4R_CHECK(Q.stats + 8, CHECK_QUEUE_LENGTH, n_in <= Q.cap)) n_in = 0;
+    float4 *const *rq = Q.ray[seg & 1u];
+    const uint32_t npix = A.npix;
+    TraceCounters cnt;
+    // A workgroup takes a pool of RAYS_PER_THREAD x 256 consecutive rays at a time -- the one at its own position in the
+    // grid first, then pools from the segment's cursor, one global atomic each -- and its waves take wave-wide groups of
+    // the pool one by one through a word in LDS (high half: end of the pool, low half: next group), so that no wave waits
+    // for another: the wave that finds the pool empty takes the lock, fetches the next pool and publishes it; the others
+    // retry until it has.  The waves of a workgroup so stay on neighbouring rays (a wave that walked a long private run
+    // of the queue instead traced 28 % slower: every wave then streams through pages of its own).
+    const uint32_t per_thread = min((uint32_t)RAYS_PER_THREAD, max(1u, (n_in + gridDim.x * BLOCK - 1u) / (gridDim.x * BLOCK)));
+    const uint32_t pool = per_thread * BLOCK;
+    __shared__ unsigned long long s_pool;  // end << 32 | next
+    __shared__ uint32_t s_lock, s_done;
+    if (threadIdx.x == 0) {
+        const uint32_t b = min(n_in, blockIdx.x * pool);
+        s_pool = (unsigned long long)min(n_in, b + pool) << 32 | b;
+        s_lock = 0u;
+        s_done = 0u;
+    }
+    __syncthreads();
+    while (true) {
+        // lane 0 finds the wave's next group of 64 rays
+        uint32_t at = 0xFFFFFFFFu;
+        if (lane_id() == 0) {
+            while (true) {
+                const unsigned long long got = atomicAdd(&s_pool, 64ull);
+                if ((uint32_t)got < (uint32_t)(got >> 32)) {
+                    at = (uint32_t)got;
+                    break;
+                }
+                if (*(volatile uint32_t *)&s_done) break;
+                if (atomicCAS(&s_lock, 0u, 1u) == 0u) {
+                    // (the pool may have been refilled between the failed take and the lock)
+                    const unsigned long long now = *(volatile unsigned long long *)&s_pool;
+                    if ((uint32_t)now >= (uint32_t)(now >> 32) && !*(volatile uint32_t *)&s_done) {
+                        const uint32_t b = gridDim.x * pool + atomicAdd(second ? &ctr->second_cursor : &ctr->trace_cursor, pool);
+                        if (b < n_in) {
+                            at = b;  // this wave takes the first group itself
+                            *(volatile unsigned long long *)&s_pool = (unsigned long long)min(n_in, b + pool) << 32 | (b + 64u);
+                        } else {
+                            *(volatile uint32_t *)&s_done = 1u;
+                        }
+                    }
+                    __threadfence_block();
+                    atomicExch(&s_lock, 0u);
+                    if (at != 0xFFFFFFFFu) break;
+                } else {
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+        }
+        at = (uint32_t)__shfl((int)at, 0, 64);
+        if (at == 0xFFFFFFFFu) break;
+        {
+            uint32_t pos = at + lane_id();
+            bool active = pos < n_in;
+            uint32_t i = active ? pos : n_in - 1u;
+            if (second) i = Q.given_up[i];
+            const uint32_t ii = i;
+            V3 o, d;
+            uint32_t pass_in_batch = 0, pixel = 0;  // PRIMARY only
+            if (PRIMARY) {
+                ray_order(A.order, S.width, npix, ii, pass_in_batch, pixel);
+                uint32_t k0, k1;
+                path_key(A.seed_lo, A.seed_hi, A.first_pass + pass_in_batch * A.pass_stride, pixel + A.pixel_offset, k0, k1);
+                camera_ray(S, pixel + A.pixel_offset, segment_key(k0, k1, 0u), false, o, d, A.order.inv_width);
+            } else {
+                float4 a = rq[0][ii];
+                o = v3(a.x, a.y, a.z);
+                float2 b = *reinterpret_cast<const float2 *>(&rq[1][ii]);
+                d = v3(a.w, b.x, b.y);
+            }
+            Best best;
+            best.t = V4R_INF;
+            best.prim = NO_PRIM;
+            best.u = best.v = 0.0f;
+            if (second) {  // the closest hit found before the ray was given up
+                float4 h = Q.hitd[ii];
+                const uint32_t w = __float_as_uint(h.y);
+                best.t = h.x;
+                best.prim = w == HIT_GIVEN_UP_NO_HIT ? NO_PRIM : (w & ~HIT_GIVEN_UP);
+                best.u = h.z;
+                best.v = h.w;
+            }
+            auto key = [&]() {
+                uint32_t k0, k1;
+                if (PRIMARY) {
+                    path_key(A.seed_lo, A.seed_hi, A.first_pass + pass_in_batch * A.pass_stride, pixel + A.pixel_offset, k0, k1);
+                } else {
+                    float4 c = rq[2][ii];
+                    k0 = __float_as_uint(c.z);
+                    k1 = __float_as_uint(c.w);
+                }
+                return segment_key(k0, k1, seg);
+            };
+            bool gave_up = traverse<COUNT, MEDIA, WIDE8>(S, o, d, active, st, best, cnt, key, second ? 0u : give_up_lanes, second);
+            asm volatile("" : "+v"(i));
+            if (active && V4R_CHECK(Q.stats + 8, CHECK_QUEUE_INDEX, i < Q.cap)) {
+                uint32_t w = best.prim;
+                if (gave_up) w = best.prim == NO_PRIM ? HIT_GIVEN_UP_NO_HIT : (best.prim | HIT_GIVEN_UP);
+                Q.hitd[i] = make_float4(best.t, __uint_as_float(w), best.u, best.v);
+                Q.hitw[i] = w;
+                // a camera ray that has hit something gets its record now (a given-up one is generated again by the second launch)
+                if (PRIMARY && !gave_up && best.prim != NO_PRIM) {
+                    PathState p;
+                    p.o = o;
+                    p.d = d;
+                    p.thr = v3(1, 1, 1);
+                    p.slot = pass_in_batch * npix + pixel;
+                    path_key(A.seed_lo, A.seed_hi, A.first_pass + pass_in_batch * A.pass_stride, pixel + A.pixel_offset, p.k0, p.k1);
+                    store_ray(rq, i, p);
+                }
+            }
+        }
+    }
+    if (COUNT) {
+        unsigned long long n = wave_sum(cnt.nodes), q = wave_sum(cnt.prims);
+        if (lane_id() == 0) {
+            atomicAdd(&Q.stats[1], n);
+            atomicAdd(&Q.stats[2], q);
+            atomicAdd(&Q.stats[6], (unsigned long long)cnt.wave_steps);
+            atomicAdd(&Q.stats[7], (unsigned long long)cnt.wave_leaves);
+        }
+    }
+}
+
+// What becomes of the rays that k_trace_only traced: see above.  SECOND: the rays of the second launch (the segment's given-up list).
+template <bool COUNT, bool PRIMARY, bool SECOND>
+__global__ __launch_bounds__(BLOCK) void k_classify(SceneDev S, Queues Q, uint32_t seg, PrimaryArgs A) {
+    constexpr int PER_THREAD = 4;
+    __shared__ uint32_t s_cnt[CLS_COUNT + 1];              // [CLS_COUNT]: rays given up
+    __shared__ uint32_t s_where[PER_THREAD * BLOCK];       // per ray of the chunk: destination << 16 | rank among the chunk's rays with that destination
+    SegCtr *ctr = Q.ctr + seg;
+    uint32_t n_in = SECOND ? ctr->given_up : (PRIMARY ? A.n_paths : rays_in(Q, seg));
+    if (!V4R_CHECK(Q.stats + 8, CHECK_QUEUE_LENGTH, n_in <= Q.cap)) n_in = 0;
+    // (in the second pass the list of given-up rays is read while nothing is appended to it)
+    float4 *const *rq = Q.ray[seg & 1u];
+    const uint32_t npix = A.npix;
+    const bool count_shape_rays = S.packet_rule != 0u && seg < V4R_PACKET_COUNTED_LEVELS;
+    uint32_t n_traced = 0, n_lights = 0;
+    constexpr uint32_t DEST_NONE = 0xFFu;
+    constexpr uint32_t chunk = PER_THREAD * BLOCK;
+    for (uint32_t base = blockIdx.x * chunk; base < n_in; base += gridDim.x * chunk) {
+        if (threadIdx.x <= CLS_COUNT) s_cnt[threadIdx.x] = 0;
+        __syncthreads();
+        // the four rays' loads go out together, level by level: index, primitive word, class word
+        uint32_t ray[PER_THREAD], word[PER_THREAD], info_of[PER_THREAD];
+        bool is_active[PER_THREAD];
+#pragma unroll
+        for (int j = 0; j < PER_THREAD; ++j) {
+            const uint32_t pos = base + j * BLOCK + threadIdx.x;
+            is_active[j] = pos < n_in;
+            ray[j] = is_active[j] ? pos : n_in - 1u;
+            if (SECOND) ray[j] = Q.given_up[ray[j]];
+            if (!V4R_CHECK(Q.stats + 8, CHECK_QUEUE_INDEX, ray[j] < Q.cap)) ray[j] = 0;
+        }
+#pragma unroll
+        for (int j = 0; j < PER_THREAD; ++j) word[j] = Q.hitw[ray[j]];
+#pragma unroll
+        for (int j = 0; j < PER_THREAD; ++j) {
+            const bool hit = word[j] != NO_PRIM && (SECOND || !(word[j] & HIT_GIVEN_UP));
+            info_of[j] = hit ? S.prim_info[word[j]] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < PER_THREAD; ++j) {
+            const uint32_t i = ray[j], w = word[j];
+            const bool active = is_active[j];
+            uint32_t dest = DEST_NONE;
+            if (active && !SECOND && w != NO_PRIM && (w & HIT_GIVEN_UP)) {
+                dest = (uint32_t)CLS_COUNT;
+            } else if (active) {
+                if (COUNT) n_traced++;
+                const uint32_t info = info_of[j], cls = info >> 24;
+                const bool counted = w != NO_PRIM && count_shape_rays && !(info & PRIM_INFO_ALWAYS_FULL);  // (a shape full in every pass is not counted at all)
+                const bool ends = w == NO_PRIM || (info & PRIM_INFO_PLAIN_LIGHT);
+                // the path's slot (and, where it ends, throughput): a camera ray's follow from its position in the queue
+                uint32_t slot = 0, pass_in_batch = 0, pixel = 0;
+                V3 thr = v3(1, 1, 1);
+                float4 a = make_float4(0, 0, 0, 0), bb = a;
+                if (PRIMARY) {
+                    if (counted || ends) ray_order(A.order, S.width, npix, i, pass_in_batch, pixel);
+                    slot = pass_in_batch * npix + pixel;
+                    if (ends && w != NO_PRIM) a = rq[0][i], bb = rq[1][i];  // (a camera ray that hit has its record: the direction)
+                } else if (counted || ends) {
+                    bb = rq[1][i];
+                    slot = __float_as_uint(bb.z);
+                    if (ends) {
+                        const float4 c = rq[2][i];
+                        thr = v3(bb.w, c.x, c.y);
+                        if (w != NO_PRIM) a = rq[0][i];
+                    }
+                }
+                uint32_t *n_rays = Q.shape_rays;
+                uint32_t full = 1u;
+                if (counted) {
+                    const uint32_t pass = PRIMARY ? pass_in_batch : pass_of_slot(slot, npix, A.inv_npix);
+                    if (V4R_CHECK(Q.stats + 8, CHECK_RAY_COUNTER, (size_t)(pass + 1u) * S.n_prims <= Q.flags_offset)) {
+                        n_rays += (size_t)pass * S.n_prims + w;
+                        full = (info & PRIM_INFO_SMALL) ? 0u : n_rays[Q.flags_offset];
+                    }
+                }
+                if (w == NO_PRIM) {  // renderer.rs:184: a miss takes the background colour
+                    Q.rad[slot] = make_float4(thr.x * S.bg[0], thr.y * S.bg[1], thr.z * S.bg[2], 0.0f);
+                } else if (info & PRIM_INFO_PLAIN_LIGHT) {
+                    // DiffuseLight (material/diffuse_light.rs:19-22) of one colour on an untransformed rectangle: the path ends
+                    // here with throughput x emitted.  The face test is HitRecord::face_normal (hittable/mod.rs:146-154).
+                    const uint4 colour = S.prim_shade[2 * (size_t)w];
+                    const float along = comp(v3(a.w, bb.x, bb.y), (int)((info >> PRIM_INFO_AXIS_SHIFT) & 3u));
+                    const bool front = ((info & PRIM_INFO_POSITIVE) ? along : -along) < 0.0f;
+                    V3 e = front ? v3(__uint_as_float(colour.y), __uint_as_float(colour.z), __uint_as_float(colour.w)) : v3(0, 0, 0);
+                    Q.rad[slot] = make_float4(thr.x * e.x, thr.y * e.y, thr.z * e.z, 0.0f);
+                    if (COUNT) n_lights++;
+                } else {
+                    dest = cls;
+                    if (counted && (cls == (uint32_t)CLS_LAMBERT || cls == (uint32_t)CLS_LAMBERT_NOISE) && full == 0u) {
+                        if (info & PRIM_INFO_SMALL) atomicAdd(n_rays, 1u);
+                        else if (atomicAdd(n_rays, 1u) + 1u >= V4R_PACKET_MANY_RAYS) n_rays[Q.flags_offset] = 1u;
+                    }
+                }
+            }
+            uint32_t where = 0xFFFFFFFFu;
+            for (unsigned long long todo = __ballot(dest != DEST_NONE); todo != 0ull;) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const uint32_t which = (uint32_t)__shfl((int)dest, leader, 64);
+                const unsigned long long same = __ballot(dest == which);
+                uint32_t first = 0u;
+                if ((int)lane_id() == leader) first = atomicAdd(&s_cnt[which], (uint32_t)__popcll(same));
+                first = (uint32_t)__shfl((int)first, leader, 64);
+                if (dest == which) where = (which << 16) | (first + (uint32_t)__popcll(same & ((1ull << lane_id()) - 1ull)));
+                todo &= ~same;
+            }
+            s_where[j * BLOCK + threadIdx.x] = where;
+        }
+        __syncthreads();
+        if (threadIdx.x <= CLS_COUNT) {
+            uint32_t n = s_cnt[threadIdx.x];
+            uint32_t *total = threadIdx.x < CLS_COUNT ? &ctr->hit_count[threadIdx.x] : &ctr->given_up;
+            s_cnt[threadIdx.x] = n ? atomicAdd(total, n) : 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PER_THREAD; ++j) {
+            const uint32_t pos = base + j * BLOCK + threadIdx.x;
+            const uint32_t where = pos < n_in ? s_where[j * BLOCK + threadIdx.x] : 0xFFFFFFFFu;
+            if (where != 0xFFFFFFFFu) {
+                const uint32_t i = SECOND ? Q.given_up[pos] : pos;
+                const uint32_t k = where >> 16, idx = s_cnt[k] + (where & 0xFFFFu);
+                if (V4R_CHECK(Q.stats + 8, CHECK_QUEUE_INDEX, idx < Q.cap && i < Q.cap)) (k < (uint32_t)CLS_COUNT ? Q.hit[k] : Q.given_up)[idx] = i;
+            }
+        }
+        __syncthreads();
+    }
+    if (COUNT) {
+        unsigned long long s = wave_sum(n_traced), l = wave_sum(n_lights);
+        if (lane_id() == 0) {
+            atomicAdd(&Q.stats[0], s);
+            atomicAdd(&Q.stats[4], l);  // lights shaded here count as shaded hits
+            atomicAdd(&Q.stats[9], l);
         }
         if (PRIMARY && !SECOND && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&Q.stats[3], (unsigned long long)A.n_paths);
     }
@@ -949,9 +1290,11 @@ struct v4r_renderer {
     uint32_t give_up_lanes = 0, give_up_segments = 0;  // see k_trace
     bool wide8 = false;          // the traversed tree is the compressed 8-wide one (wide_step8), else the 4-wide one
     bool dense = false;          // the later segments' trace launches run 6 waves/SIMD (TREE_8_WIDE_DENSE)
+    bool split = false;          // (experiment, V4R_SPLIT=1) a segment's traversal and the classification of its hits are separate kernels (k_trace_only + k_classify)
     uint32_t tile_passes_log2 = 4;  // passes per wave tile of the camera-ray order (see ray_order)
     size_t ctr_bytes = 0;
     uint32_t max_depth = 0, spill_depth = 0;
+    std::vector<uint32_t> scene_index;     // the scene's index of the device's primitive k (build())
     unsigned char *scratch_ptr = nullptr;  // this device's copy of `scratch`
     Pipe noalloc;                          // queues carved out of it (Q.cap = 0: the scene does not fit), on the public stream
 
@@ -1007,7 +1350,7 @@ int validate(const v4r_scene_desc *d, uint32_t &depth_out) {
     if (d->abi_version != V4R_ABI_VERSION) return set_error(V4R_E_INVALID, "scene description has a different ABI version");
     if (d->width == 0 || d->height == 0) return set_error(V4R_E_INVALID, "width and height must be positive");
     if ((uint64_t)d->width * d->height > (1ull << 28)) return set_error(V4R_E_LIMIT, "image larger than 2^28 pixels");
-    if (d->n_prims > 0x7FFFFFFFu) return set_error(V4R_E_LIMIT, "too many primitives");
+    if (d->n_prims > LEAF_FIRST_MASK) return set_error(V4R_E_LIMIT, "more than 2^28 - 1 primitives");
     auto need = [&](const void *p, uint32_t n, const char *name) {
         return (n != 0 && p == nullptr) ? set_error(V4R_E_INVALID, std::string(name) + " table is NULL") : V4R_OK;
     };
@@ -1144,11 +1487,15 @@ uint32_t grid_for(K kernel, int n_cu) {
 }
 
 // A binary tree over the leaf boxes of the host's tree, split by the usual binned surface-area
-// heuristic (16 bins per axis, all three axes, true surface area), one primitive per leaf, in the
-// node format of the ABI.  The reference's builder (bvh.rs:84-141: 6 buckets, widest centroid axis
-// only, squared-extent "area") stays the host's; the closest hit does not depend on the tree, and
-// rays visit 5-15 % fewer nodes in this one.  V4R_FLAG_KEEP_HOST_BVH skips it.
-void rebuild_binary(const v4r_scene_desc *d, bool without_media, std::vector<v4r_bvh_node> &out) {
+// heuristic (16 bins per axis, all three axes, true surface area), in the node format of the ABI.
+// The reference's builder (bvh.rs:84-141: 6 buckets, widest centroid axis only, squared-extent
+// "area", one shape per leaf) stays the host's; the closest hit does not depend on the tree, and
+// rays visit fewer nodes in this one.  V4R_FLAG_KEEP_HOST_BVH skips it.
+// A leaf is a block of up to `leaf_max` primitives: the tree stops splitting a range that small (a constant medium is
+// always a leaf of its own: its subtree must never be culled, see wide_step).  `order` receives the primitives in the
+// order of the tree's leaves -- the device's own numbering of the primitives, under which a leaf's block is a run
+// of consecutive records -- and a leaf's child word is leaf_word(first position in `order`, count).
+void rebuild_binary(const v4r_scene_desc *d, bool without_media, uint32_t leaf_max, std::vector<v4r_bvh_node> &out, std::vector<uint32_t> &order) {
     struct Box {
         float lo[3], hi[3];
     };
@@ -1185,10 +1532,20 @@ void rebuild_binary(const v4r_scene_desc *d, bool without_media, std::vector<v4r
         float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
         return dx * dy + dy * dz + dz * dx;
     };
-    std::vector<uint32_t> order;
+    auto is_medium = [&](uint32_t p) { return (d->prims[p].type & V4R_PRIM_TYPE_MASK) == V4R_PRIM_MEDIUM; };
+    order.clear();
     order.reserve(d->n_prims);
     for (uint32_t i = 0; i < d->n_prims; ++i)
-        if (!without_media || (d->prims[i].type & V4R_PRIM_TYPE_MASK) != V4R_PRIM_MEDIUM) order.push_back(i);
+        if (!without_media || !is_medium(i)) order.push_back(i);
+    // a range becomes one leaf when it is short enough and holds no constant medium (unless it is a single primitive)
+    auto is_leaf = [&](uint32_t begin, uint32_t end) {
+        if (end - begin == 1) return true;
+        if (end - begin > leaf_max) return false;
+        if (d->n_media != 0)
+            for (uint32_t i = begin; i < end; ++i)
+                if (is_medium(order[i])) return false;
+        return true;
+    };
     out.clear();
     out.reserve(d->n_nodes);
     struct Task {
@@ -1201,7 +1558,7 @@ void rebuild_binary(const v4r_scene_desc *d, bool without_media, std::vector<v4r
         Task t = todo.back();
         todo.pop_back();
         uint32_t n = t.end - t.begin;
-        // a range of one primitive is a leaf word in its parent; larger ranges become interior nodes
+        // a short range is a leaf word in its parent (is_leaf); the others become interior nodes
         uint32_t self = (uint32_t)out.size();
         out.emplace_back();
         if (t.slot >= 0) (t.slot == 0 ? out[t.node].child0 : out[t.node].child1) = self;
@@ -1274,9 +1631,9 @@ void rebuild_binary(const v4r_scene_desc *d, bool without_media, std::vector<v4r
         std::memcpy(nd.hi0, l.hi, 12);
         std::memcpy(nd.lo1, r.lo, 12);
         std::memcpy(nd.hi1, r.hi, 12);
-        if (mid - t.begin == 1) nd.child0 = V4R_LEAF_BIT | order[t.begin];
+        if (is_leaf(t.begin, mid)) nd.child0 = leaf_word(t.begin, mid - t.begin);
         else todo.push_back({t.begin, mid, self, 0});
-        if (t.end - mid == 1) nd.child1 = V4R_LEAF_BIT | order[mid];
+        if (is_leaf(mid, t.end)) nd.child1 = leaf_word(mid, t.end - mid);
         else todo.push_back({mid, t.end, self, 1});
     }
 }
@@ -1299,7 +1656,7 @@ uint32_t collapse_to_wide(const v4r_scene_desc *d, const v4r_bvh_node *nodes, ui
     // which subtrees of the binary tree hold a constant medium (wide_step must not cull those by distance)
     std::vector<uint8_t> holds_medium(n_nodes, 0);
     if (d->n_media != 0) {
-        auto leaf_is_medium = [&](uint32_t word) { return (d->prims[word & ~V4R_LEAF_BIT].type & V4R_PRIM_TYPE_MASK) == V4R_PRIM_MEDIUM; };
+        auto leaf_is_medium = [&](uint32_t word) { return (d->prims[leaf_first(word)].type & V4R_PRIM_TYPE_MASK) == V4R_PRIM_MEDIUM; };
         std::vector<std::pair<uint32_t, bool>> walk{{0u, false}};  // (node, children done)
         while (!walk.empty()) {
             auto [node, done] = walk.back();
@@ -1318,7 +1675,7 @@ uint32_t collapse_to_wide(const v4r_scene_desc *d, const v4r_bvh_node *nodes, ui
     }
     auto never_cull = [&](uint32_t word) {
         if (d->n_media == 0) return false;
-        if (word & V4R_LEAF_BIT) return (d->prims[word & ~V4R_LEAF_BIT].type & V4R_PRIM_TYPE_MASK) == V4R_PRIM_MEDIUM;
+        if (word & V4R_LEAF_BIT) return (d->prims[leaf_first(word)].type & V4R_PRIM_TYPE_MASK) == V4R_PRIM_MEDIUM;
         return holds_medium[word] != 0;
     };
     struct Item {
@@ -1537,6 +1894,7 @@ int ensure_pipe(v4r_renderer *r, Pipe &pipe, size_t need, size_t n_passes) {
     for (int k = 0; k < CLS_COUNT; ++k)
         if (int rc = alloc(&Q.hit[k], r->has_class[k] ? need : 1)) return rc;
     if (int rc = alloc(&Q.hitd, need)) return rc;
+    if (int rc = alloc(&Q.hitw, need)) return rc;
     if (int rc = alloc(&Q.given_up, need)) return rc;
     if (int rc = alloc(&Q.rad, need)) return rc;
     if (int rc = alloc(&Q.ctr, (size_t)r->max_depth + 1)) return rc;
@@ -1600,7 +1958,7 @@ void carve_noalloc(v4r_renderer *r, int n_cu) {
     }
     // per path slot: two ray queues of three 16-byte columns, the hit record, the radiance slot, the given-up index
     // and one index per material class
-    const size_t per_slot = 2 * 3 * sizeof(float4) + 2 * sizeof(float4) + (1 + CLS_COUNT) * sizeof(uint32_t);
+    const size_t per_slot = 2 * 3 * sizeof(float4) + 2 * sizeof(float4) + (2 + CLS_COUNT) * sizeof(uint32_t);
     size_t cap = ((size_t)V4R_NOALLOC_SCRATCH_BYTES - off) / per_slot;
     cap = cap > 4096 ? (cap - 4096) & ~(size_t)63 : 0;  // room for the 256-byte alignment of each of the 15 arrays
     if (cap == 0) return;
@@ -1608,13 +1966,13 @@ void carve_noalloc(v4r_renderer *r, int n_cu) {
     for (int p = 0; p < 2; ++p)
         for (int c = 0; c < 3; ++c) ok = ok && take(&Q.ray[p][c], cap);
     for (int k = 0; k < CLS_COUNT; ++k) ok = ok && take(&Q.hit[k], cap);
-    ok = ok && take(&Q.hitd, cap) && take(&Q.given_up, cap) && take(&Q.rad, cap);
+    ok = ok && take(&Q.hitd, cap) && take(&Q.hitw, cap) && take(&Q.given_up, cap) && take(&Q.rad, cap);
     if (!ok) return;
     Q.stats = r->stats;
     Q.cap = (uint32_t)cap;
 }
 
-int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
+int build(v4r_renderer *r, const v4r_scene_desc *given, uint32_t bvh_depth) {
     (void)bvh_depth;  // the traversal stack is sized by the wide tree made below
     uint32_t wide_depth = 0, wide_depth8 = 0, n_top8 = 0, n_nodes8 = 0;  // deepest traversal stack of either tree
     const float4 *nodes8 = nullptr;  // the 8-wide tree, when the scene has one
@@ -1625,25 +1983,60 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     HIP_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
 
     SceneDev &S = r->S;
+    // A few constant media are tested directly, before the tree, by the kernels without the medium code in their
+    // traversal (see traverse): the tree is then built over the other primitives.
+    size_t n_media_prims = 0;
+    for (uint32_t i = 0; i < given->n_prims; ++i)
+        if ((given->prims[i].type & V4R_PRIM_TYPE_MASK) == V4R_PRIM_MEDIUM) ++n_media_prims;
+    const bool keep_host_tree = (given->flags & V4R_FLAG_KEEP_HOST_BVH) != 0 || given->n_nodes == 0;
+    const bool direct = !keep_host_tree && n_media_prims != 0 && n_media_prims <= MAX_DIRECT_MEDIA && given->n_prims - n_media_prims >= 2;
+    r->media_mode = direct ? MEDIA_DIRECT : (given->n_media != 0 ? MEDIA_IN_TREE : MEDIA_NONE);
+    // The device's own numbering of the primitives: the order of the leaves of the tree it builds, so that the primitives
+    // of a leaf -- and of neighbouring leaves -- are neighbours in every per-primitive table.  r->scene_index[k] is the
+    // scene's index (Scene::hittables, scene.rs:20-23) of the device's primitive k: the closest-hit rule orders equal
+    // distances by it (consider), and the entry points that return primitive indices translate through it.  The scene's
+    // own tree (V4R_FLAG_KEEP_HOST_BVH, or a scene of one shape) keeps the scene's numbering.
+    uint32_t leaf_max = V4R_LEAF_PRIMS;
+    if (const char *env = std::getenv("V4R_LEAF_PRIMS")) leaf_max = (uint32_t)std::max(1, std::min((int)V4R_LEAF_PRIMS, std::atoi(env)));
+    std::vector<v4r_bvh_node> better;
+    std::vector<uint32_t> &scene_index = r->scene_index;
+    if (!keep_host_tree) {
+        rebuild_binary(given, direct, leaf_max, better, scene_index);
+        if (direct)
+            for (uint32_t i = 0; i < given->n_prims; ++i)
+                if ((given->prims[i].type & V4R_PRIM_TYPE_MASK) == V4R_PRIM_MEDIUM) scene_index.push_back(i);  // outside the tree: numbered last
+    } else {
+        scene_index.resize(given->n_prims);
+        for (uint32_t i = 0; i < given->n_prims; ++i) scene_index[i] = i;
+    }
+    std::vector<uint32_t> device_index(given->n_prims);
+    for (uint32_t k = 0; k < given->n_prims; ++k) device_index[scene_index[k]] = k;
+    std::vector<v4r_prim> prims_in_order(given->n_prims);
+    std::vector<uint32_t> materials_in_order(given->n_prims), lights_renumbered(given->n_lights);
+    for (uint32_t k = 0; k < given->n_prims; ++k) {
+        prims_in_order[k] = given->prims[scene_index[k]];
+        materials_in_order[k] = given->prim_material[scene_index[k]];
+    }
+    for (uint32_t l = 0; l < given->n_lights; ++l) lights_renumbered[l] = device_index[given->lights[l]];
+    // from here on `d` is the scene under the device's numbering; `given` keeps the scene's tree
+    v4r_scene_desc renumbered = *given;
+    renumbered.prims = prims_in_order.data();
+    renumbered.prim_material = materials_in_order.data();
+    renumbered.lights = lights_renumbered.data();
+    const v4r_scene_desc *d = &renumbered;
+    if (int rc = r->upload(&S.scene_index, scene_index.data(), scene_index.size())) return rc;
     {
         std::vector<float4> wide;
-        // A few constant media are tested directly, before the tree, by the kernels without the medium code in their
-        // traversal (see traverse): the tree is then built over the other primitives.
-        std::vector<uint32_t> media_list;
-        for (uint32_t i = 0; i < d->n_prims; ++i)
-            if ((d->prims[i].type & V4R_PRIM_TYPE_MASK) == V4R_PRIM_MEDIUM) media_list.push_back(i);
-        const bool direct = !(d->flags & V4R_FLAG_KEEP_HOST_BVH) && !media_list.empty() && media_list.size() <= MAX_DIRECT_MEDIA &&
-                            d->n_prims - media_list.size() >= 2;
         if (direct) {
+            std::vector<uint32_t> media_list;
+            for (uint32_t k = 0; k < d->n_prims; ++k)
+                if ((d->prims[k].type & V4R_PRIM_TYPE_MASK) == V4R_PRIM_MEDIUM) media_list.push_back(k);
             if (int rc = r->upload(&S.media_direct, media_list.data(), media_list.size())) return rc;
             S.n_media_direct = (uint32_t)media_list.size();
         }
-        r->media_mode = direct ? MEDIA_DIRECT : (d->n_media != 0 ? MEDIA_IN_TREE : MEDIA_NONE);
-        std::vector<v4r_bvh_node> better;
-        const v4r_bvh_node *binary = d->nodes;
-        uint32_t n_binary = d->n_nodes;
-        if (!(d->flags & V4R_FLAG_KEEP_HOST_BVH) && d->n_nodes > 0) {
-            rebuild_binary(d, direct, better);
+        const v4r_bvh_node *binary = given->nodes;
+        uint32_t n_binary = given->n_nodes;
+        if (!keep_host_tree) {
             binary = better.data();
             n_binary = (uint32_t)better.size();
         }
@@ -1654,7 +2047,7 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
         bool encodable = true;
         wide_depth = collapse_to_wide<4>(d, binary, n_binary, wide, S.n_top_nodes, encodable);
         if (int rc = r->upload(&S.nodes4, wide.data(), wide.size())) return rc;
-        if (!(d->flags & V4R_FLAG_KEEP_HOST_BVH) && n_binary > 0) {
+        if (!keep_host_tree && n_binary > 0) {
             wide_depth8 = collapse_to_wide<8>(d, binary, n_binary, wide8, n_top8, encodable);
             if (encodable) {
                 if (int rc = r->upload(&nodes8, wide8.data(), wide8.size())) return rc;
@@ -1735,6 +2128,7 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     S.n_nodes = d->n_nodes;
     r->give_up_lanes = 12;
     r->give_up_segments = 8;
+    if (const char *env = std::getenv("V4R_SPLIT")) r->split = std::atoi(env) != 0;
     if (const char *env = std::getenv("V4R_GIVE_UP_LANES")) r->give_up_lanes = (uint32_t)std::max(0, std::min(63, std::atoi(env)));
     if (const char *env = std::getenv("V4R_TILE_PASSES_LOG2")) r->tile_passes_log2 = (uint32_t)std::min(6, std::max(0, std::atoi(env)));
     if (const char *env = std::getenv("V4R_GIVE_UP_SEGMENTS")) r->give_up_segments = (uint32_t)std::max(0, std::atoi(env));
@@ -1751,8 +2145,8 @@ int build(v4r_renderer *r, const v4r_scene_desc *d, uint32_t bvh_depth) {
     S.antialias = d->antialias;
 
     r->npix = d->width * d->height;
-    if (int rc = r->alloc(&r->stats, 16)) return rc;
-    HIP_TRY(hipMemset(r->stats, 0, 128));
+    if (int rc = r->alloc(&r->stats, 64)) return rc;
+    HIP_TRY(hipMemset(r->stats, 0, 512));
     // Which tree: the deterministic camera rays (one through each pixel centre) are traced through both with the work counted;
     // the 8-wide tree is kept when its node steps, priced at WIDE8_STEP_COST steps of the 4-wide tree, and its extra leaf
     // steps come to less.  The counts are exact, so the choice is a function of the scene (V4R_WIDE=4|8 forces one).
@@ -1941,13 +2335,23 @@ uint32_t launch_trace_as(v4r_renderer *r, Pipe &pipe, uint32_t seg, const Primar
     uint32_t give_up = seg < r->give_up_segments ? r->give_up_lanes : 0u;
     auto launch = [&](auto tree) {
         constexpr int TREE = decltype(tree)::value;
+        if (r->split) {
+            dim3 grid_classify(r->grid_stream);
+            hipLaunchKernelGGL((k_trace_only<COUNT, R, MEDIA, PRIMARY, false, TREE>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A, give_up);
+            hipLaunchKernelGGL((k_classify<COUNT, PRIMARY, false>), grid_classify, block, 0, pipe.stream, r->S, pipe.Q, seg, A);
+            if (give_up) {
+                hipLaunchKernelGGL((k_trace_only<COUNT, R, MEDIA, PRIMARY, true, TREE>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A, 0u);
+                hipLaunchKernelGGL((k_classify<COUNT, PRIMARY, true>), grid_classify, block, 0, pipe.stream, r->S, pipe.Q, seg, A);
+            }
+            return;
+        }
         hipLaunchKernelGGL((k_trace<COUNT, R, MEDIA, PRIMARY, false, TREE>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A, give_up);
         if (give_up) hipLaunchKernelGGL((k_trace<COUNT, R, MEDIA, PRIMARY, true, TREE>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A, 0u);
     };
     if (!r->wide8) launch(std::integral_constant<int, TREE_4_WIDE>{});
     else if (MEDIA == MEDIA_NONE && !PRIMARY && r->dense) launch(std::integral_constant<int, MEDIA == MEDIA_NONE && !PRIMARY ? TREE_8_WIDE_DENSE : TREE_8_WIDE>{});
     else launch(std::integral_constant<int, TREE_8_WIDE>{});
-    return give_up ? 2u : 1u;
+    return (give_up ? 2u : 1u) * (r->split ? 2u : 1u);
 }
 template <bool COUNT, int MEDIA>
 uint32_t launch_trace_media(v4r_renderer *r, Pipe &pipe, uint32_t seg, const PrimaryArgs &A) {
@@ -2386,7 +2790,12 @@ static int trace_common(v4r_renderer *r, uint32_t n, const float *host_origin, c
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
-    if (e == hipSuccess && host_prim_id) e = hipMemcpy(host_prim_id, d_p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && host_prim_id) {
+        e = hipMemcpy(host_prim_id, d_p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+        if (e == hipSuccess)  // the device numbers the primitives in the order of its tree's leaves
+            for (uint32_t i = 0; i < n; ++i)
+                if (host_prim_id[i] < r->scene_index.size()) host_prim_id[i] = r->scene_index[host_prim_id[i]];
+    }
     if (e == hipSuccess && host_t) e = hipMemcpy(host_t, d_t, (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
     cleanup();
     if (e != hipSuccess) return set_error(V4R_E_HIP, std::string("trace: ") + hipGetErrorString(e));
@@ -2428,6 +2837,20 @@ int v4r_stats_read(v4r_renderer *r, v4r_stats *out, int reset) {
     out->wave_node_steps = h[6];
     out->wave_leaf_steps = h[7];
     out->ended_on_light = h[9];
+#ifdef V4R_PHASE_CLOCKS
+    {
+        unsigned long long c[24];
+        HIP_TRY(hipMemcpy(c, r->stats + 16, sizeof c, hipMemcpyDeviceToHost));
+        static const char *kind[3] = {"camera rays", "later segments", "second launches"};
+        for (int k = 0; k < 3; ++k)
+            std::fprintf(stderr, "v4r phase clocks, %s: wave-rays %llu; cycles per wave-ray: fetch %.0f, node steps %.0f, leaf phases %.0f, traverse %.0f, "
+                         "end of ray %.0f, chunk %.0f, wave lifetime %.0f\n", kind[k], c[8 * k + 7], (double)c[8 * k] / std::max(1ull, c[8 * k + 7]),
+                         (double)c[8 * k + 1] / std::max(1ull, c[8 * k + 7]), (double)c[8 * k + 2] / std::max(1ull, c[8 * k + 7]),
+                         (double)c[8 * k + 3] / std::max(1ull, c[8 * k + 7]), (double)c[8 * k + 4] / std::max(1ull, c[8 * k + 7]),
+                         (double)c[8 * k + 5] / std::max(1ull, c[8 * k + 7]), (double)c[8 * k + 6] / std::max(1ull, c[8 * k + 7]));
+        if (reset) HIP_TRY(hipMemset(r->stats + 16, 0, sizeof c));
+    }
+#endif
     if (reset) {
         HIP_TRY(hipMemsetAsync(r->stats, 0, 64, r->stream));  // ordered before whatever is rendered next
         HIP_TRY(hipMemsetAsync(r->stats + 9, 0, 8, r->stream));

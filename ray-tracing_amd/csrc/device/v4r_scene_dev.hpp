@@ -20,6 +20,20 @@ enum {
 };
 
 constexpr uint32_t NO_PRIM = 0xFFFFFFFFu;
+// A leaf of the traversed tree is a block of 1 to LEAF_MAX_PRIMS primitives that are consecutive in the device's numbering:
+// child word = V4R_LEAF_BIT | (count - 1) << 28 | first.  (0xFFFFFFFF stays "no entry": the last primitive index is never used.)
+constexpr uint32_t LEAF_FIRST_MASK = (1u << 28) - 1u, LEAF_MAX_PRIMS = 8u;
+constexpr uint32_t leaf_word(uint32_t first, uint32_t count) { return V4R_LEAF_BIT | (count - 1u) << 28 | first; }
+constexpr uint32_t leaf_first(uint32_t word) { return word & LEAF_FIRST_MASK; }
+constexpr uint32_t leaf_count(uint32_t word) { return (word >> 28 & 7u) + 1u; }
+// Primitives per leaf that the kernels are built for.  1: as in the reference's tree (bvh.rs:10-12).  Larger blocks were
+// measured and lose: an 8-wide node over eight one-primitive leaves culls most of them for the price of 1.6 primitive
+// tests, where a block tests every one of its primitives (builds with -DV4R_LEAF_PRIMS=2|4|8 keep the experiment
+// reproducible; V4R_LEAF_PRIMS in the environment then selects any size up to the built one).
+#ifndef V4R_LEAF_PRIMS
+#define V4R_LEAF_PRIMS 1
+#endif
+static_assert(V4R_LEAF_PRIMS >= 1 && V4R_LEAF_PRIMS <= 8, "a leaf word counts 1 to 8 primitives");
 // prim_info word: material index (18 bits) | flags | shading class << 24
 constexpr uint32_t PRIM_INFO_ALWAYS_FULL = 1u << 18;  // a Lambertian shape that so many camera rays end on that it is "full" (packet rule) in every pass
 constexpr uint32_t SHADE_ALWAYS_FULL = 1u;            // the same, in the padding word of the shape's prim_shade record
@@ -45,6 +59,7 @@ struct SceneDev {
     const float4 *perlin_vec;    // 256 x float4 per table
     const uint8_t *perlin_perm;  // 768 bytes per table: perm_x, perm_y, perm_z
     const uint32_t *lights;      // primitive indices
+    const uint32_t *scene_index; // per primitive: its index in the scene (the device numbers primitives in the order of its tree's leaves)
     uint32_t n_nodes, n_prims, n_lights, flags;
     const uint32_t *media_direct;  // primitives (constant media) tested before the tree instead of inside it
     uint32_t n_media_direct;
@@ -137,7 +152,18 @@ V4R_DEV void to_object(const float *x, V3 &o, V3 &d, float &nrm) {
 struct TraceCounters {
     uint32_t nodes = 0, prims = 0;
     uint32_t wave_steps = 0, wave_leaves = 0;  // counted by every lane of the wave, whether it takes part or not
+#ifdef V4R_PHASE_CLOCKS
+    // A build for measurements only (-DV4R_PHASE_CLOCKS, with the work counters on): shader clock cycles a wave spends in
+    // each part of k_trace, every part closed by a wait for its outstanding memory operations.
+    unsigned long long clk_node = 0, clk_leaf = 0;
+#endif
 };
+#ifdef V4R_PHASE_CLOCKS
+V4R_DEV unsigned long long phase_clock() {
+    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0): the part that ends here has waited for its loads
+    return __builtin_amdgcn_s_memtime();
+}
+#endif
 
 // Closest hit so far during traversal.
 struct Best {
@@ -217,12 +243,14 @@ V4R_DEV void consider(const SceneDev &S, uint32_t prim_index, V3 o, V3 d, Best &
         float nrm = 1.0f;
         uint32_t xf = pr.xform();
         if (xf != V4R_NO_XFORM) to_object(S.xforms + 24 * (size_t)xf, o, d, nrm);
-        hit = medium_t(S, pr, prim_index, o, d, EPSILON * nrm, V4R_INF * nrm, t, key);
+        // (the free path is drawn from the dimension of the medium's index in the scene)
+        hit = medium_t(S, pr, S.scene_index[prim_index], o, d, EPSILON * nrm, V4R_INF * nrm, t, key);
         if (xf != V4R_NO_XFORM) t = t / nrm;
     } else {
         hit = solid_t(S, pr, o, d, EPSILON, V4R_INF, t, u, v);
     }
-    if (hit && (t < best.t || (t == best.t && prim_index < best.prim))) {
+    // equal distances: the shape of lower index in the scene wins, whatever the device's numbering (looked up only then)
+    if (hit && (t < best.t || (t == best.t && best.prim != NO_PRIM && S.scene_index[prim_index] < S.scene_index[best.prim]))) {
         best.t = t;
         best.prim = prim_index;
         best.u = u;
@@ -515,14 +543,25 @@ V4R_DEV void wide_step(const SceneDev &S, V3 o, V3 inv, Stack &st, const Best &b
     }
 }
 
-// Intersect the parked primitive of every lane of the wave, then pop what each of those lanes does next.
+// Intersect the parked leaf of every lane of the wave -- a block of consecutive primitives -- then pop what each of
+// those lanes does next.
 template <bool COUNT, bool MEDIA, class KeyFn, class Stack>
 V4R_DEV void wide_leaves(const SceneDev &S, V3 o, V3 d, Stack &st, Best &best, Wide &W, TraceCounters &cnt, KeyFn key) {
     bool parked = W.parked();
     if (COUNT) cnt.wave_leaves++;
     if (parked) {
+#if V4R_LEAF_PRIMS > 1
+        // (the block is walked inside the leaf word itself -- first + 1, count - 1 -- so that the loop keeps no register of its own)
+        while (true) {
+            if (COUNT) cnt.prims++;
+            consider<MEDIA>(S, leaf_first(W.cur), o, d, best, key);
+            if ((W.cur >> 28 & 7u) == 0u) break;
+            W.cur -= (1u << 28) - 1u;
+        }
+#else
         if (COUNT) cnt.prims++;
-        consider<MEDIA>(S, W.cur & ~V4R_LEAF_BIT, o, d, best, key);
+        consider<MEDIA>(S, leaf_first(W.cur), o, d, best, key);
+#endif
         wide_pop(st, best.t, W);
     }
 }
@@ -575,12 +614,24 @@ V4R_DEV bool traverse(const SceneDev &S, V3 o, V3 d, bool active, Stack &st, Bes
             if (m_parked != 0ull && __popcll(m_parked) * V4R_VOTE_DEN >= (__popcll(m_parked) + __popcll(m_step)) * V4R_VOTE_NUM) break;
             if (COUNT) cnt.wave_steps++;
             ++steps;
+#ifdef V4R_PHASE_CLOCKS
+            const unsigned long long t0 = COUNT ? phase_clock() : 0ull;
+#endif
             if (W.stepping()) {
                 if (WIDE8) wide_step8<COUNT, MEDIA == MEDIA_IN_TREE>(S, o, inv, st, best, W, cnt);
                 else wide_step<COUNT, MEDIA == MEDIA_IN_TREE>(S, o, inv, st, best, W, cnt);
             }
+#ifdef V4R_PHASE_CLOCKS
+            if (COUNT) cnt.clk_node += phase_clock() - t0;
+#endif
         }
+#ifdef V4R_PHASE_CLOCKS
+        const unsigned long long t1 = COUNT ? phase_clock() : 0ull;
+#endif
         if (__ballot(W.parked()) != 0ull) wide_leaves<COUNT, MEDIA == MEDIA_IN_TREE>(S, o, d, st, best, W, cnt, key);
+#ifdef V4R_PHASE_CLOCKS
+        if (COUNT) cnt.clk_leaf += phase_clock() - t1;
+#endif
         if (__ballot(W.cur != TRAV_NONE) == 0ull) break;
     }
     return false;
