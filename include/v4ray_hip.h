@@ -33,7 +33,7 @@ extern "C" {
 #define V4R_E_NO_DEVICE (-2)   /* no usable gfx950 device / HIP runtime failure at set-up       */
 #define V4R_E_HIP (-3)         /* a HIP call failed (message in v4r_last_error)                 */
 #define V4R_E_UNSUPPORTED (-4) /* scene uses a feature the device path does not implement       */
-#define V4R_E_LIMIT (-5)       /* a size exceeds a documented limit (e.g. BVH depth > stack)    */
+#define V4R_E_LIMIT (-5)       /* a size exceeds a documented limit (e.g. more than 2^28 - 1 primitives) */
 
 /* ---- geometry tables ---------------------------------------------------------------------- */
 
@@ -313,6 +313,33 @@ int v4r_trace_primary(v4r_renderer *r, uint32_t *host_prim_id, float *host_t);
  * Maps to BVH::traverse + Hittable::hit (src/hittable/mod.rs:180-182). */
 int v4r_trace_rays(v4r_renderer *r, uint32_t n, const float *host_origin, const float *host_dir,
                    uint64_t seed, uint32_t *host_prim_id, float *host_t);
+
+/* The tree the kernels traverse, for checkers and tools.  The device library does not walk `nodes` of the scene
+ * description as given (unless V4R_FLAG_KEEP_HOST_BVH): it re-splits the same leaf boxes, numbers the primitives in the
+ * order of its own tree's leaves and collapses the binary tree into 4-wide or 8-wide nodes of 128 bytes, whichever
+ * does less work for the scene's camera rays.  v4r_tree_read copies that tree out: `nodes` receives n_nodes * 128 bytes,
+ * `scene_index` n_prims words (scene_index[k] = index in the scene description of the primitive the device calls k),
+ * `media_direct` n_media_direct words (device numbers of the constant media that every ray tests before the tree
+ * instead of meeting them as leaves); any of the three may be NULL.
+ *   Child word: an interior node's index; or V4R_LEAF_BIT | (count - 1) << 28 | first = the leaf holding the device's
+ *   primitives first .. first + count - 1; or 0xFFFFFFFF = empty slot.
+ *   4-wide node, 32 floats: lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4] child[4] {never-cull mask, 0, 0, 0}; an empty
+ *   slot has NaN planes.
+ *   8-wide node: {p.x, p.y, p.z, biased exponents ex | ey << 8 | ez << 16 | never-cull mask << 24}, child[8], then the
+ *   children's planes as bytes, eight each (two words, child c in byte c & 3 of word c >> 2): lower x, lower y, lower z,
+ *   upper x, upper y, upper z; plane = p + byte * 2^(e - 127).  The last 32 bytes are zero.
+ *   Never-cull mask: children whose subtree holds a constant medium, entered whenever the ray meets their box.
+ * No counterpart in the reference, whose BVH is private to its Renderer (src/bvh/bvh.rs:156-160, src/renderer.rs:75-82). */
+typedef struct v4r_tree_info {
+    uint32_t width;          /* children per node: 4 or 8 */
+    uint32_t n_nodes;        /* 128-byte nodes; 0 for a scene of one primitive, which is tested without any box */
+    uint32_t n_top_nodes;    /* the first n_top_nodes nodes are the top levels, breadth first (kept in LDS by the kernels) */
+    uint32_t n_prims;
+    uint32_t n_media_direct;
+    uint32_t media_in_tree;  /* 1: constant media are leaves of the tree and the never-cull masks are in use */
+    uint32_t pad[2];
+} v4r_tree_info;
+int v4r_tree_read(v4r_renderer *r, v4r_tree_info *info, void *nodes, uint32_t *scene_index, uint32_t *media_direct);
 
 /* Enable/disable the traversal work counters (an instrumented kernel variant) and read them. */
 int v4r_stats_enable(v4r_renderer *r, int on);

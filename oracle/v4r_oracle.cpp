@@ -16,17 +16,23 @@
 // packed_simd comparisons/transcendentals, rand's gen_range) is restated from those crates'
 // published definitions.
 //
-// Deliberate, documented departures (none changes the estimator):
+// Deliberate, documented departures:
 //  * Random numbers: the reference draws from an OS-seeded ThreadRng (random.rs:6-16), which is
 //    irreproducible.  Here every draw is a pure function of (seed, pass, pixel, segment,
 //    dimension) -- the same counter-based generator the device uses -- so oracle and device
 //    trace the same paths and can be compared per pixel.
 //  * Packets: the reference processes 8 rays per SIMD packet.  Per-lane results do not depend
-//    on the other lanes except in Samplable::value for rectangles and triangles
-//    (aa_rect.rs:158-179, triangle.rs:110-131), where a lane that misses the light still gets
-//    the un-clipped plane density whenever ANY lane of its packet hits.  Scalar restatement:
-//    the plane density always (default), or the textbook bounded density under
-//    V4R_FLAG_BOUNDED_LIGHT_PDF.
+//    on the other lanes except in two places: HittableGroup::generate draws one light index per
+//    packet (group.rs:91-95), and Samplable::value for rectangles and triangles
+//    (aa_rect.rs:158-179, triangle.rs:110-131) gives a lane that misses the light the un-clipped
+//    plane density when some lane of its packet hits it and 0 when none does.  Render mode 2
+//    restates the packets themselves (render_pass_packets: rays regrouped by closest shape,
+//    packets of 8 in first-hit order, renderer.rs:131-298).  The per-ray modes follow the scene's
+//    flags, like the device: no flag = the packet-statistics rule (lights_value_stat: the packet
+//    rule in expectation, from the number of rays of the pass and level that end on the shape),
+//    V4R_FLAG_PLANE_LIGHT_PDF = the plane density always, V4R_FLAG_BOUNDED_LIGHT_PDF = 0 for a
+//    direction that misses (the textbook density).  Only mode 2 is the reference's estimator
+//    sample for sample; the packet-statistics rule has its mean (measured in the GPU tests).
 //  * Recursion: ray_color's breadth-first recursion (renderer.rs:123-320) is run per path as a
 //    loop carrying the product of the per-bounce coefficients; colour = emitted + coef * child
 //    unrolls to the same sum of products.
@@ -539,6 +545,117 @@ void traverse_wide(Ctx &ctx, const WideTree &tree, const Ray &r, Closest &c) {
     }
 }
 
+// ---- the device's own tree, walked with the device's arithmetic (trace mode 4) --------------------------------------
+// For the work counters of the tree that is actually timed: the device library builds a tree of its own from the
+// scene's leaf boxes (4-wide, or 8-wide with the children's boxes on an 8-bit grid; leaves may hold several
+// primitives) and hands it out through v4r_tree_read (include/v4ray_hip.h documents the node formats).  The walk
+// below restates the kernels' node step one ray at a time: same operations in the same order on the same node words,
+// so it visits the nodes and tests the primitives the device does; the closest hit is the reference's (consider()).
+struct DeviceTree {
+    v4r_tree_info info{};
+    std::vector<uint32_t> nodes;        // 32 words per node
+    std::vector<uint32_t> scene_index;  // the scene's index of the device's primitive k
+    std::vector<uint32_t> media_direct; // constant media every ray tests before the tree (device numbering)
+};
+DeviceTree g_device_tree;
+
+inline float as_float(uint32_t u) {
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+inline uint32_t as_bits(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    return u;
+}
+
+void traverse_device_tree(Ctx &ctx, const DeviceTree &T, const Ray &r, Closest &c) {
+    for (uint32_t k : T.media_direct) consider(ctx, c, T.scene_index[k], r);
+    struct Entry {
+        uint32_t child;
+        float entry;
+    };
+    std::vector<Entry> stack;
+    const bool wide8 = T.info.width == 8;
+    float inv[3] = {1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
+    if (wide8)
+        for (float &v : inv) v = std::fmin(std::fmax(v, -1e18f), 1e18f);
+    const float o[3] = {r.o.x, r.o.y, r.o.z};
+    const bool masks = T.info.media_in_tree != 0;
+    uint32_t cur = 0;
+    while (true) {
+        if (cur & V4R_LEAF_BIT) {
+            const uint32_t first = cur & ((1u << 28) - 1u), count = (cur >> 28 & 7u) + 1u;
+            for (uint32_t k = 0; k < count; ++k) consider(ctx, c, T.scene_index[first + k], r);
+        } else {
+            const uint32_t *w = T.nodes.data() + 32 * (size_t)cur;
+            ctx.cnt.nodes++;
+            uint32_t key[8], child[8], never_cull = 0;
+            const int width = wide8 ? 8 : 4;
+            if (wide8) {
+                const uint32_t bits = w[3];
+                never_cull = masks ? bits >> 24 & 255u : 0u;
+                float a[3], b[3];
+                for (int k = 0; k < 3; ++k) {
+                    a[k] = (as_float(w[k]) - o[k]) * inv[k];
+                    b[k] = as_float((bits >> (8 * k) & 255u) << 23) * inv[k];
+                }
+                for (int ch = 0; ch < 8; ++ch) {
+                    child[ch] = w[4 + ch];
+                    // words 12-17: lower x, y, z planes (two words each: children 0-3, 4-7), words 18-23: the upper planes
+                    auto byte = [&](int plane) { return (float)(w[12 + 2 * plane + (ch >> 2)] >> (8 * (ch & 3)) & 255u); };
+                    float entry = EPSILON, leave = INF;
+                    float near_d[3], far_d[3];
+                    for (int k = 0; k < 3; ++k) {
+                        const bool down = inv[k] < 0.0f;  // the ray meets the upper plane first
+                        near_d[k] = std::fma(byte(down ? 3 + k : k), b[k], a[k]);
+                        far_d[k] = std::fma(byte(down ? k : 3 + k), b[k], a[k]);
+                    }
+                    entry = std::fmax(std::fmax(near_d[0], near_d[1]), std::fmax(near_d[2], EPSILON));
+                    leave = std::fmin(std::fmin(far_d[0], far_d[1]), far_d[2]);
+                    const bool wanted = entry <= c.hit.t || (never_cull >> ch & 1u);
+                    key[ch] = (entry < leave && wanted && child[ch] != 0xFFFFFFFFu) ? ((as_bits(entry) & ~7u) | (uint32_t)ch) : 0xFFFFFFFFu;
+                }
+            } else {
+                never_cull = masks ? w[28] : 0u;
+                for (int ch = 0; ch < 4; ++ch) {
+                    child[ch] = w[24 + ch];
+                    float lo_d[3], hi_d[3];
+                    for (int k = 0; k < 3; ++k) {
+                        lo_d[k] = (as_float(w[4 * k + ch]) - o[k]) * inv[k];
+                        hi_d[k] = (as_float(w[12 + 4 * k + ch]) - o[k]) * inv[k];
+                    }
+                    const float entry = std::fmax(std::fmax(std::fmin(lo_d[0], hi_d[0]), std::fmin(lo_d[1], hi_d[1])), std::fmax(std::fmin(lo_d[2], hi_d[2]), EPSILON));
+                    const float leave = std::fmin(std::fmin(std::fmax(lo_d[0], hi_d[0]), std::fmax(lo_d[1], hi_d[1])), std::fmax(lo_d[2], hi_d[2]));
+                    const bool wanted = entry <= c.hit.t || (never_cull >> ch & 1u);
+                    key[ch] = (entry < leave && wanted) ? ((as_bits(entry) & ~3u) | (uint32_t)ch) : 0xFFFFFFFFu;
+                }
+            }
+            std::sort(key, key + width);
+            const uint32_t slot_mask = (uint32_t)width - 1u;
+            auto entry_of = [&](uint32_t k) { return (never_cull >> (k & slot_mask) & 1u) ? -INF : as_float(k & ~slot_mask); };
+            for (int k = width - 1; k >= 1; --k)
+                if (key[k] != 0xFFFFFFFFu) stack.push_back({child[key[k] & slot_mask], entry_of(key[k])});
+            if (key[0] != 0xFFFFFFFFu) {
+                cur = child[key[0] & slot_mask];
+                continue;
+            }
+        }
+        bool found = false;
+        while (!stack.empty()) {
+            Entry e = stack.back();
+            stack.pop_back();
+            if (e.entry <= c.hit.t) {
+                cur = e.child;
+                found = true;
+                break;
+            }
+        }
+        if (!found) return;
+    }
+}
+
 Closest trace(Ctx &ctx, const Ray &r, int mode) {
     Closest c;
     ctx.cnt.segments++;
@@ -548,7 +665,8 @@ Closest trace(Ctx &ctx, const Ray &r, int mode) {
         consider(ctx, c, 0, r);
         return c;
     }
-    if (mode == 1) traverse_wide(ctx, *ctx.wide, r, c);
+    if (mode == 4 && g_device_tree.info.n_nodes != 0) traverse_device_tree(ctx, g_device_tree, r, c);
+    else if (mode == 1) traverse_wide(ctx, *ctx.wide, r, c);
     else traverse_reference(ctx, 0, r, c);
     return c;
 }
@@ -1119,7 +1237,7 @@ void parallel_for(uint32_t n, int n_threads, F body) {  // body(begin, end, thre
 }
 
 // rule 2: the reference's packets; rule 3: the packet-statistics rule (per-ray shading, per-shape ray counts of the level)
-// trace_mode: 0 = the reference's candidate-set traversal, 1 = the device's ordered traversal of `wide` (same hits).
+// trace_mode: 0 = the reference's candidate-set traversal, 1 = the device's ordered traversal of `wide`, 4 = of the device's own tree (same hits).
 void render_pass_packets(const v4r_scene_desc *s, uint64_t seed, uint32_t pass, float *accum, int n_threads, std::vector<Counters> &counters,
                          int rule, int trace_mode, const WideTree *wide) {
     const uint32_t npix = s->width * s->height;
@@ -1253,7 +1371,7 @@ const char *v4o_last_error(void) { return g_error.c_str(); }
 // reference's candidate-set traversal; 1 = the device's ordered traversal; both with the light pdf the scene's
 // flags select, like the device (no flag: the packet-statistics rule, lights_value_stat);
 // 2 = the reference's breadth-first pass with its 8-lane packets (render_pass_packets); 3 = the
-// packet-statistics rule whatever the flags.
+// packet-statistics rule whatever the flags; 4 = as 1, but walking the tree set by v4o_set_device_tree.
 // pixel_stride > 1 renders only pixels whose index is a multiple of it (for strided work counts;
 // modes 0 and 1).
 int v4o_render(const v4r_scene_desc *s, uint64_t seed, uint32_t first_pass, uint32_t pass_stride, uint32_t n_passes,
@@ -1290,7 +1408,7 @@ int v4o_render(const v4r_scene_desc *s, uint64_t seed, uint32_t first_pass, uint
     // work counts, keeps the per-path loop and the plane density: the paths are the same, only their weights differ).
     const bool packet_rule = s->n_lights != 0 && !(s->flags & (V4R_FLAG_BOUNDED_LIGHT_PDF | V4R_FLAG_PLANE_LIGHT_PDF));
     if (mode == 2 || mode == 3 || (packet_rule && pixel_stride == 1)) {  // whole passes, breadth first
-        const int rule = mode == 2 ? 2 : 3, trace_mode = mode == 1 ? 1 : 0;
+        const int rule = mode == 2 ? 2 : 3, trace_mode = mode == 1 ? 1 : (mode == 4 ? 4 : 0);
         // Whole passes run concurrently, as the reference runs them (main.rs:56-63: one task per pass): `outer` passes at a
         // time, each on `inner` threads and into its own buffer; a pass adds exactly one term per pixel, so adding the
         // buffers in pass order gives the bits of a sequential loop.  `outer` is bounded by the passes asked for and by
@@ -1351,21 +1469,42 @@ int v4o_render(const v4r_scene_desc *s, uint64_t seed, uint32_t first_pass, uint
     return V4R_OK;
 }
 
-// Deterministic primary rays (pixel centres, no lens sample): closest primitive and t per pixel.
+// The tree of a device renderer (v4r_tree_read) for trace mode 4; NULL info clears it.  Not thread safe against running renders.
+int v4o_set_device_tree(const v4r_tree_info *info, const void *nodes, const uint32_t *scene_index, const uint32_t *media_direct) {
+    g_device_tree = DeviceTree{};
+    if (!info) return V4R_OK;
+    if ((info->width != 4 && info->width != 8) || (info->n_nodes && !nodes) || (info->n_prims && !scene_index) || (info->n_media_direct && !media_direct)) {
+        g_error = "malformed device tree";
+        return V4R_E_INVALID;
+    }
+    g_device_tree.info = *info;
+    g_device_tree.nodes.assign((const uint32_t *)nodes, (const uint32_t *)nodes + 32 * (size_t)info->n_nodes);
+    g_device_tree.scene_index.assign(scene_index, scene_index + info->n_prims);
+    if (info->n_media_direct) g_device_tree.media_direct.assign(media_direct, media_direct + info->n_media_direct);
+    return V4R_OK;
+}
+
+// Deterministic primary rays (pixel centres, no lens sample): closest primitive and t per pixel.  Rows are handed
+// out to every hardware thread (each ray is independent).
 int v4o_trace_primary(const v4r_scene_desc *s, uint32_t *prim_id, float *t, int mode) {
     if (int rc = validate(s)) return rc;
-    Ctx ctx{s};
     WideTree wide;
     if (mode == 1) wide = build_wide(s);
-    ctx.wide = &wide;
-    uint32_t npix = s->width * s->height;
-    for (uint32_t pix = 0; pix < npix; ++pix) {
-        Ray r = camera_ray(s, pix / s->width, pix % s->width, 0, true);
-        ctx.seg_key = 0;
-        Closest c = trace(ctx, r, mode);
-        if (prim_id) prim_id[pix] = c.prim;
-        if (t) t[pix] = c.hit.t;
-    }
+    const uint32_t npix = s->width * s->height;
+    int n_threads = (int)std::thread::hardware_concurrency();
+    if (n_threads <= 0) n_threads = 1;
+    if (npix < 65536u) n_threads = 1;
+    parallel_for(npix, n_threads, [&](uint32_t b, uint32_t e, int) {
+        Ctx ctx{s};
+        ctx.wide = &wide;
+        for (uint32_t pix = b; pix < e; ++pix) {
+            Ray r = camera_ray(s, pix / s->width, pix % s->width, 0, true);
+            ctx.seg_key = 0;
+            Closest c = trace(ctx, r, mode);
+            if (prim_id) prim_id[pix] = c.prim;
+            if (t) t[pix] = c.hit.t;
+        }
+    });
     return V4R_OK;
 }
 

@@ -64,7 +64,6 @@ struct Queues {
     float4 *ray[2][3];          // [segment parity][column]: {o.xyz,d.x} {d.yz,slot,thr.r} {thr.gb,k0,k1}
     uint32_t *hit[CLS_COUNT];   // per shading class: the indices (into the ray queue of the segment) of the rays that hit it
     float4 *hitd;               // {t, prim, u, v} of ray i of the segment being traced
-    uint32_t *hitw;             // the primitive word of hitd[i] once more, for k_classify (which then reads 4 instead of 16 bytes per ray)
     uint32_t *given_up;         // indices of the rays whose wave gave them up (see traverse); traced by a second launch
     float4 *rad;                // per path slot: radiance of the finished path
     SegCtr *ctr;                // [max_depth + 1]
@@ -552,302 +551,6 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
     }
 }
 
-// ---- the same segment as two kernels: traversal only, then a streaming classification ---------------------------
-// k_trace_only is k_trace without everything that follows a ray's closest hit: it writes the hit record of every ray
-// (misses and given-up rays included) and nothing else -- no primitive-class lookup, no ray counters, no radiance of
-// ended paths, no ranking, no workgroup barrier, no queue.  A wave, not a workgroup, is the unit that takes chunks of
-// the queue.  k_classify then streams over the hit records with every lane busy and does what k_trace did at the end
-// of each ray: end the paths that missed or met a plain light, count rays per shape (packet rule), rank the others
-// within their shading class and append their indices to the class queues (and the given-up rays to theirs).
-#ifndef V4R_TRACE_RUN_MAX
-#define V4R_TRACE_RUN_MAX 4096  // rays a wave takes from the queue at once, at most
-#endif
-constexpr uint32_t HIT_GIVEN_UP = 0x40000000u;        // in the primitive word of a hit record: the wave gave this ray up (primitive indices stay below 2^28)
-constexpr uint32_t HIT_GIVEN_UP_NO_HIT = 0xFFFFFFFEu;  // ... before it had hit anything
-template <bool COUNT, int RAYS_PER_THREAD, int MEDIA, bool PRIMARY, bool SECOND, int TREE>
-__global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES_MEDIA : (PRIMARY ? V4R_TRACE_MIN_WAVES_PRIMARY : (MEDIA == MEDIA_DIRECT ? V4R_TRACE_MIN_WAVES_DIRECT : (TREE == TREE_8_WIDE_DENSE ? V4R_TRACE_WAVES_DENSE : V4R_TRACE_MIN_WAVES)))) void k_trace_only(SceneDev S, Queues Q, uint32_t seg, PrimaryArgs A, uint32_t give_up_lanes) {
-    constexpr bool second = SECOND;
-    constexpr bool WIDE8 = TREE != TREE_4_WIDE;
-    __shared__ uint2 lds_stack[lds_depth(WIDE8) * BLOCK];
-    __shared__ v4f s_top[8 * (WIDE8 ? TOP_NODES_8 : TOP_NODES)];
-    StackT<lds_depth(WIDE8)> st;
-    stage_tree_top(S, s_top, st);
-    __syncthreads();
-    st.lds = (lds_uint2 *)lds_stack + threadIdx.x;
-    st.stride = BLOCK;
-    st.spill = Q.spill + (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    st.spill_stride = Q.spill_stride;
-    st.sp = 0;
-#ifdef V4R_DEBUG_CHECKS
-    st.errors = Q.stats + 8;
-    st.spill_depth = (int)Q.spill_depth;
-#endif
-    SegCtr *ctr = Q.ctr + seg;
-    uint32_t n_in = second ? ctr->given_up : (PRIMARY ? A.n_paths : rays_in(Q, seg));
-    if (!V4R_CHECK(Q.stats + 8, CHECK_QUEUE_LENGTH, n_in <= Q.cap)) n_in = 0;
-    float4 *const *rq = Q.ray[seg & 1u];
-    const uint32_t npix = A.npix;
-    TraceCounters cnt;
-    // A workgroup takes a pool of RAYS_PER_THREAD x 256 consecutive rays at a time -- the one at its own position in the
-    // grid first, then pools from the segment's cursor, one global atomic each -- and its waves take wave-wide groups of
-    // the pool one by one through a word in LDS (high half: end of the pool, low half: next group), so that no wave waits
-    // for another: the wave that finds the pool empty takes the lock, fetches the next pool and publishes it; the others
-    // retry until it has.  The waves of a workgroup so stay on neighbouring rays (a wave that walked a long private run
-    // of the queue instead traced 28 % slower: every wave then streams through pages of its own).
-    const uint32_t per_thread = min((uint32_t)RAYS_PER_THREAD, max(1u, (n_in + gridDim.x * BLOCK - 1u) / (gridDim.x * BLOCK)));
-    const uint32_t pool = per_thread * BLOCK;
-    __shared__ unsigned long long s_pool;  // end << 32 | next
-    __shared__ uint32_t s_lock, s_done;
-    if (threadIdx.x == 0) {
-        const uint32_t b = min(n_in, blockIdx.x * pool);
-        s_pool = (unsigned long long)min(n_in, b + pool) << 32 | b;
-        s_lock = 0u;
-        s_done = 0u;
-    }
-    __syncthreads();
-    while (true) {
-        // lane 0 finds the wave's next group of 64 rays
-        uint32_t at = 0xFFFFFFFFu;
-        if (lane_id() == 0) {
-            while (true) {
-                const unsigned long long got = atomicAdd(&s_pool, 64ull);
-                if ((uint32_t)got < (uint32_t)(got >> 32)) {
-                    at = (uint32_t)got;
-                    break;
-                }
-                if (*(volatile uint32_t *)&s_done) break;
-                if (atomicCAS(&s_lock, 0u, 1u) == 0u) {
-                    // (the pool may have been refilled between the failed take and the lock)
-                    const unsigned long long now = *(volatile unsigned long long *)&s_pool;
-                    if ((uint32_t)now >= (uint32_t)(now >> 32) && !*(volatile uint32_t *)&s_done) {
-                        const uint32_t b = gridDim.x * pool + atomicAdd(second ? &ctr->second_cursor : &ctr->trace_cursor, pool);
-                        if (b < n_in) {
-                            at = b;  // this wave takes the first group itself
-                            *(volatile unsigned long long *)&s_pool = (unsigned long long)min(n_in, b + pool) << 32 | (b + 64u);
-                        } else {
-                            *(volatile uint32_t *)&s_done = 1u;
-                        }
-                    }
-                    __threadfence_block();
-                    atomicExch(&s_lock, 0u);
-                    if (at != 0xFFFFFFFFu) break;
-                } else {
-                    __builtin_amdgcn_s_sleep(2);
-                }
-            }
-        }
-        at = (uint32_t)__shfl((int)at, 0, 64);
-        if (at == 0xFFFFFFFFu) break;
-        {
-            uint32_t pos = at + lane_id();
-            bool active = pos < n_in;
-            uint32_t i = active ? pos : n_in - 1u;
-            if (second) i = Q.given_up[i];
-            const uint32_t ii = i;
-            V3 o, d;
-            uint32_t pass_in_batch = 0, pixel = 0;  // PRIMARY only
-            if (PRIMARY) {
-                ray_order(A.order, S.width, npix, ii, pass_in_batch, pixel);
-                uint32_t k0, k1;
-                path_key(A.seed_lo, A.seed_hi, A.first_pass + pass_in_batch * A.pass_stride, pixel + A.pixel_offset, k0, k1);
-                camera_ray(S, pixel + A.pixel_offset, segment_key(k0, k1, 0u), false, o, d, A.order.inv_width);
-            } else {
-                float4 a = rq[0][ii];
-                o = v3(a.x, a.y, a.z);
-                float2 b = *reinterpret_cast<const float2 *>(&rq[1][ii]);
-                d = v3(a.w, b.x, b.y);
-            }
-            Best best;
-            best.t = V4R_INF;
-            best.prim = NO_PRIM;
-            best.u = best.v = 0.0f;
-            if (second) {  // the closest hit found before the ray was given up
-                float4 h = Q.hitd[ii];
-                const uint32_t w = __float_as_uint(h.y);
-                best.t = h.x;
-                best.prim = w == HIT_GIVEN_UP_NO_HIT ? NO_PRIM : (w & ~HIT_GIVEN_UP);
-                best.u = h.z;
-                best.v = h.w;
-            }
-            auto key = [&]() {
-                uint32_t k0, k1;
-                if (PRIMARY) {
-                    path_key(A.seed_lo, A.seed_hi, A.first_pass + pass_in_batch * A.pass_stride, pixel + A.pixel_offset, k0, k1);
-                } else {
-                    float4 c = rq[2][ii];
-                    k0 = __float_as_uint(c.z);
-                    k1 = __float_as_uint(c.w);
-                }
-                return segment_key(k0, k1, seg);
-            };
-            bool gave_up = traverse<COUNT, MEDIA, WIDE8>(S, o, d, active, st, best, cnt, key, second ? 0u : give_up_lanes, second);
-            asm volatile("" : "+v"(i));
-            if (active && V4R_CHECK(Q.stats + 8, CHECK_QUEUE_INDEX, i < Q.cap)) {
-                uint32_t w = best.prim;
-                if (gave_up) w = best.prim == NO_PRIM ? HIT_GIVEN_UP_NO_HIT : (best.prim | HIT_GIVEN_UP);
-                Q.hitd[i] = make_float4(best.t, __uint_as_float(w), best.u, best.v);
-                Q.hitw[i] = w;
-                // a camera ray that has hit something gets its record now (a given-up one is generated again by the second launch)
-                if (PRIMARY && !gave_up && best.prim != NO_PRIM) {
-                    PathState p;
-                    p.o = o;
-                    p.d = d;
-                    p.thr = v3(1, 1, 1);
-                    p.slot = pass_in_batch * npix + pixel;
-                    path_key(A.seed_lo, A.seed_hi, A.first_pass + pass_in_batch * A.pass_stride, pixel + A.pixel_offset, p.k0, p.k1);
-                    store_ray(rq, i, p);
-                }
-            }
-        }
-    }
-    if (COUNT) {
-        unsigned long long n = wave_sum(cnt.nodes), q = wave_sum(cnt.prims);
-        if (lane_id() == 0) {
-            atomicAdd(&Q.stats[1], n);
-            atomicAdd(&Q.stats[2], q);
-            atomicAdd(&Q.stats[6], (unsigned long long)cnt.wave_steps);
-            atomicAdd(&Q.stats[7], (unsigned long long)cnt.wave_leaves);
-        }
-    }
-}
-
-// What becomes of the rays that k_trace_only traced: see above.  SECOND: the rays of the second launch (the segment's given-up list).
-template <bool COUNT, bool PRIMARY, bool SECOND>
-__global__ __launch_bounds__(BLOCK) void k_classify(SceneDev S, Queues Q, uint32_t seg, PrimaryArgs A) {
-    constexpr int PER_THREAD = 4;
-    __shared__ uint32_t s_cnt[CLS_COUNT + 1];              // [CLS_COUNT]: rays given up
-    __shared__ uint32_t s_where[PER_THREAD * BLOCK];       // per ray of the chunk: destination << 16 | rank among the chunk's rays with that destination
-    SegCtr *ctr = Q.ctr + seg;
-    uint32_t n_in = SECOND ? ctr->given_up : (PRIMARY ? A.n_paths : rays_in(Q, seg));
-    if (!V4R_CHECK(Q.stats + 8, CHECK_QUEUE_LENGTH, n_in <= Q.cap)) n_in = 0;
-    // (in the second pass the list of given-up rays is read while nothing is appended to it)
-    float4 *const *rq = Q.ray[seg & 1u];
-    const uint32_t npix = A.npix;
-    const bool count_shape_rays = S.packet_rule != 0u && seg < V4R_PACKET_COUNTED_LEVELS;
-    uint32_t n_traced = 0, n_lights = 0;
-    constexpr uint32_t DEST_NONE = 0xFFu;
-    constexpr uint32_t chunk = PER_THREAD * BLOCK;
-    for (uint32_t base = blockIdx.x * chunk; base < n_in; base += gridDim.x * chunk) {
-        if (threadIdx.x <= CLS_COUNT) s_cnt[threadIdx.x] = 0;
-        __syncthreads();
-        // the four rays' loads go out together, level by level: index, primitive word, class word
-        uint32_t ray[PER_THREAD], word[PER_THREAD], info_of[PER_THREAD];
-        bool is_active[PER_THREAD];
-#pragma unroll
-        for (int j = 0; j < PER_THREAD; ++j) {
-            const uint32_t pos = base + j * BLOCK + threadIdx.x;
-            is_active[j] = pos < n_in;
-            ray[j] = is_active[j] ? pos : n_in - 1u;
-            if (SECOND) ray[j] = Q.given_up[ray[j]];
-            if (!V4R_CHECK(Q.stats + 8, CHECK_QUEUE_INDEX, ray[j] < Q.cap)) ray[j] = 0;
-        }
-#pragma unroll
-        for (int j = 0; j < PER_THREAD; ++j) word[j] = Q.hitw[ray[j]];
-#pragma unroll
-        for (int j = 0; j < PER_THREAD; ++j) {
-            const bool hit = word[j] != NO_PRIM && (SECOND || !(word[j] & HIT_GIVEN_UP));
-            info_of[j] = hit ? S.prim_info[word[j]] : 0u;
-        }
-#pragma unroll
-        for (int j = 0; j < PER_THREAD; ++j) {
-            const uint32_t i = ray[j], w = word[j];
-            const bool active = is_active[j];
-            uint32_t dest = DEST_NONE;
-            if (active && !SECOND && w != NO_PRIM && (w & HIT_GIVEN_UP)) {
-                dest = (uint32_t)CLS_COUNT;
-            } else if (active) {
-                if (COUNT) n_traced++;
-                const uint32_t info = info_of[j], cls = info >> 24;
-                const bool counted = w != NO_PRIM && count_shape_rays && !(info & PRIM_INFO_ALWAYS_FULL);  // (a shape full in every pass is not counted at all)
-                const bool ends = w == NO_PRIM || (info & PRIM_INFO_PLAIN_LIGHT);
-                // the path's slot (and, where it ends, throughput): a camera ray's follow from its position in the queue
-                uint32_t slot = 0, pass_in_batch = 0, pixel = 0;
-                V3 thr = v3(1, 1, 1);
-                float4 a = make_float4(0, 0, 0, 0), bb = a;
-                if (PRIMARY) {
-                    if (counted || ends) ray_order(A.order, S.width, npix, i, pass_in_batch, pixel);
-                    slot = pass_in_batch * npix + pixel;
-                    if (ends && w != NO_PRIM) a = rq[0][i], bb = rq[1][i];  // (a camera ray that hit has its record: the direction)
-                } else if (counted || ends) {
-                    bb = rq[1][i];
-                    slot = __float_as_uint(bb.z);
-                    if (ends) {
-                        const float4 c = rq[2][i];
-                        thr = v3(bb.w, c.x, c.y);
-                        if (w != NO_PRIM) a = rq[0][i];
-                    }
-                }
-                uint32_t *n_rays = Q.shape_rays;
-                uint32_t full = 1u;
-                if (counted) {
-                    const uint32_t pass = PRIMARY ? pass_in_batch : pass_of_slot(slot, npix, A.inv_npix);
-                    if (V4R_CHECK(Q.stats + 8, CHECK_RAY_COUNTER, (size_t)(pass + 1u) * S.n_prims <= Q.flags_offset)) {
-                        n_rays += (size_t)pass * S.n_prims + w;
-                        full = (info & PRIM_INFO_SMALL) ? 0u : n_rays[Q.flags_offset];
-                    }
-                }
-                if (w == NO_PRIM) {  // renderer.rs:184: a miss takes the background colour
-                    Q.rad[slot] = make_float4(thr.x * S.bg[0], thr.y * S.bg[1], thr.z * S.bg[2], 0.0f);
-                } else if (info & PRIM_INFO_PLAIN_LIGHT) {
-                    // DiffuseLight (material/diffuse_light.rs:19-22) of one colour on an untransformed rectangle: the path ends
-                    // here with throughput x emitted.  The face test is HitRecord::face_normal (hittable/mod.rs:146-154).
-                    const uint4 colour = S.prim_shade[2 * (size_t)w];
-                    const float along = comp(v3(a.w, bb.x, bb.y), (int)((info >> PRIM_INFO_AXIS_SHIFT) & 3u));
-                    const bool front = ((info & PRIM_INFO_POSITIVE) ? along : -along) < 0.0f;
-                    V3 e = front ? v3(__uint_as_float(colour.y), __uint_as_float(colour.z), __uint_as_float(colour.w)) : v3(0, 0, 0);
-                    Q.rad[slot] = make_float4(thr.x * e.x, thr.y * e.y, thr.z * e.z, 0.0f);
-                    if (COUNT) n_lights++;
-                } else {
-                    dest = cls;
-                    if (counted && (cls == (uint32_t)CLS_LAMBERT || cls == (uint32_t)CLS_LAMBERT_NOISE) && full == 0u) {
-                        if (info & PRIM_INFO_SMALL) atomicAdd(n_rays, 1u);
-                        else if (atomicAdd(n_rays, 1u) + 1u >= V4R_PACKET_MANY_RAYS) n_rays[Q.flags_offset] = 1u;
-                    }
-                }
-            }
-            uint32_t where = 0xFFFFFFFFu;
-            for (unsigned long long todo = __ballot(dest != DEST_NONE); todo != 0ull;) {
-                const int leader = __ffsll((long long)todo) - 1;
-                const uint32_t which = (uint32_t)__shfl((int)dest, leader, 64);
-                const unsigned long long same = __ballot(dest == which);
-                uint32_t first = 0u;
-                if ((int)lane_id() == leader) first = atomicAdd(&s_cnt[which], (uint32_t)__popcll(same));
-                first = (uint32_t)__shfl((int)first, leader, 64);
-                if (dest == which) where = (which << 16) | (first + (uint32_t)__popcll(same & ((1ull << lane_id()) - 1ull)));
-                todo &= ~same;
-            }
-            s_where[j * BLOCK + threadIdx.x] = where;
-        }
-        __syncthreads();
-        if (threadIdx.x <= CLS_COUNT) {
-            uint32_t n = s_cnt[threadIdx.x];
-            uint32_t *total = threadIdx.x < CLS_COUNT ? &ctr->hit_count[threadIdx.x] : &ctr->given_up;
-            s_cnt[threadIdx.x] = n ? atomicAdd(total, n) : 0u;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < PER_THREAD; ++j) {
-            const uint32_t pos = base + j * BLOCK + threadIdx.x;
-            const uint32_t where = pos < n_in ? s_where[j * BLOCK + threadIdx.x] : 0xFFFFFFFFu;
-            if (where != 0xFFFFFFFFu) {
-                const uint32_t i = SECOND ? Q.given_up[pos] : pos;
-                const uint32_t k = where >> 16, idx = s_cnt[k] + (where & 0xFFFFu);
-                if (V4R_CHECK(Q.stats + 8, CHECK_QUEUE_INDEX, idx < Q.cap && i < Q.cap)) (k < (uint32_t)CLS_COUNT ? Q.hit[k] : Q.given_up)[idx] = i;
-            }
-        }
-        __syncthreads();
-    }
-    if (COUNT) {
-        unsigned long long s = wave_sum(n_traced), l = wave_sum(n_lights);
-        if (lane_id() == 0) {
-            atomicAdd(&Q.stats[0], s);
-            atomicAdd(&Q.stats[4], l);  // lights shaded here count as shaded hits
-            atomicAdd(&Q.stats[9], l);
-        }
-        if (PRIMARY && !SECOND && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&Q.stats[3], (unsigned long long)A.n_paths);
-    }
-}
-
 // Material::emitted + Material::scatter + the pdf branch of ray_color (renderer.rs:218-263) for one hit of
 // material class CLS, then `colors += coef * child` carried forward as the path throughput
 // (renderer.rs:299-318).  `dcol` is the hit as k_trace leaves it: distance, primitive, triangle barycentrics.
@@ -1290,11 +993,12 @@ struct v4r_renderer {
     uint32_t give_up_lanes = 0, give_up_segments = 0;  // see k_trace
     bool wide8 = false;          // the traversed tree is the compressed 8-wide one (wide_step8), else the 4-wide one
     bool dense = false;          // the later segments' trace launches run 6 waves/SIMD (TREE_8_WIDE_DENSE)
-    bool split = false;          // (experiment, V4R_SPLIT=1) a segment's traversal and the classification of its hits are separate kernels (k_trace_only + k_classify)
     uint32_t tile_passes_log2 = 4;  // passes per wave tile of the camera-ray order (see ray_order)
     size_t ctr_bytes = 0;
     uint32_t max_depth = 0, spill_depth = 0;
     std::vector<uint32_t> scene_index;     // the scene's index of the device's primitive k (build())
+    uint32_t n_wide_nodes = 0;             // nodes of the tree the kernels traverse (S.nodes4)
+    std::vector<uint32_t> media_direct;    // constant media tested before the tree (device numbering)
     unsigned char *scratch_ptr = nullptr;  // this device's copy of `scratch`
     Pipe noalloc;                          // queues carved out of it (Q.cap = 0: the scene does not fit), on the public stream
 
@@ -1894,7 +1598,6 @@ int ensure_pipe(v4r_renderer *r, Pipe &pipe, size_t need, size_t n_passes) {
     for (int k = 0; k < CLS_COUNT; ++k)
         if (int rc = alloc(&Q.hit[k], r->has_class[k] ? need : 1)) return rc;
     if (int rc = alloc(&Q.hitd, need)) return rc;
-    if (int rc = alloc(&Q.hitw, need)) return rc;
     if (int rc = alloc(&Q.given_up, need)) return rc;
     if (int rc = alloc(&Q.rad, need)) return rc;
     if (int rc = alloc(&Q.ctr, (size_t)r->max_depth + 1)) return rc;
@@ -1958,7 +1661,7 @@ void carve_noalloc(v4r_renderer *r, int n_cu) {
     }
     // per path slot: two ray queues of three 16-byte columns, the hit record, the radiance slot, the given-up index
     // and one index per material class
-    const size_t per_slot = 2 * 3 * sizeof(float4) + 2 * sizeof(float4) + (2 + CLS_COUNT) * sizeof(uint32_t);
+    const size_t per_slot = 2 * 3 * sizeof(float4) + 2 * sizeof(float4) + (1 + CLS_COUNT) * sizeof(uint32_t);
     size_t cap = ((size_t)V4R_NOALLOC_SCRATCH_BYTES - off) / per_slot;
     cap = cap > 4096 ? (cap - 4096) & ~(size_t)63 : 0;  // room for the 256-byte alignment of each of the 15 arrays
     if (cap == 0) return;
@@ -1966,7 +1669,7 @@ void carve_noalloc(v4r_renderer *r, int n_cu) {
     for (int p = 0; p < 2; ++p)
         for (int c = 0; c < 3; ++c) ok = ok && take(&Q.ray[p][c], cap);
     for (int k = 0; k < CLS_COUNT; ++k) ok = ok && take(&Q.hit[k], cap);
-    ok = ok && take(&Q.hitd, cap) && take(&Q.hitw, cap) && take(&Q.given_up, cap) && take(&Q.rad, cap);
+    ok = ok && take(&Q.hitd, cap) && take(&Q.given_up, cap) && take(&Q.rad, cap);
     if (!ok) return;
     Q.stats = r->stats;
     Q.cap = (uint32_t)cap;
@@ -2033,6 +1736,7 @@ int build(v4r_renderer *r, const v4r_scene_desc *given, uint32_t bvh_depth) {
                 if ((d->prims[k].type & V4R_PRIM_TYPE_MASK) == V4R_PRIM_MEDIUM) media_list.push_back(k);
             if (int rc = r->upload(&S.media_direct, media_list.data(), media_list.size())) return rc;
             S.n_media_direct = (uint32_t)media_list.size();
+            r->media_direct = media_list;
         }
         const v4r_bvh_node *binary = given->nodes;
         uint32_t n_binary = given->n_nodes;
@@ -2047,6 +1751,7 @@ int build(v4r_renderer *r, const v4r_scene_desc *given, uint32_t bvh_depth) {
         bool encodable = true;
         wide_depth = collapse_to_wide<4>(d, binary, n_binary, wide, S.n_top_nodes, encodable);
         if (int rc = r->upload(&S.nodes4, wide.data(), wide.size())) return rc;
+        r->n_wide_nodes = (uint32_t)(wide.size() / 8);
         if (!keep_host_tree && n_binary > 0) {
             wide_depth8 = collapse_to_wide<8>(d, binary, n_binary, wide8, n_top8, encodable);
             if (encodable) {
@@ -2128,7 +1833,6 @@ int build(v4r_renderer *r, const v4r_scene_desc *given, uint32_t bvh_depth) {
     S.n_nodes = d->n_nodes;
     r->give_up_lanes = 12;
     r->give_up_segments = 8;
-    if (const char *env = std::getenv("V4R_SPLIT")) r->split = std::atoi(env) != 0;
     if (const char *env = std::getenv("V4R_GIVE_UP_LANES")) r->give_up_lanes = (uint32_t)std::max(0, std::min(63, std::atoi(env)));
     if (const char *env = std::getenv("V4R_TILE_PASSES_LOG2")) r->tile_passes_log2 = (uint32_t)std::min(6, std::max(0, std::atoi(env)));
     if (const char *env = std::getenv("V4R_GIVE_UP_SEGMENTS")) r->give_up_segments = (uint32_t)std::max(0, std::atoi(env));
@@ -2196,6 +1900,7 @@ int build(v4r_renderer *r, const v4r_scene_desc *given, uint32_t bvh_depth) {
         if (r->wide8) {
             S.nodes4 = nodes8;
             S.n_top_nodes = n_top8;
+            r->n_wide_nodes = n_nodes8;
             wide_depth = wide_depth8;
             // six waves per SIMD for the later segments (TREE_8_WIDE_DENSE): every scene without media
             r->dense = r->media_mode == MEDIA_NONE;
@@ -2335,23 +2040,13 @@ uint32_t launch_trace_as(v4r_renderer *r, Pipe &pipe, uint32_t seg, const Primar
     uint32_t give_up = seg < r->give_up_segments ? r->give_up_lanes : 0u;
     auto launch = [&](auto tree) {
         constexpr int TREE = decltype(tree)::value;
-        if (r->split) {
-            dim3 grid_classify(r->grid_stream);
-            hipLaunchKernelGGL((k_trace_only<COUNT, R, MEDIA, PRIMARY, false, TREE>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A, give_up);
-            hipLaunchKernelGGL((k_classify<COUNT, PRIMARY, false>), grid_classify, block, 0, pipe.stream, r->S, pipe.Q, seg, A);
-            if (give_up) {
-                hipLaunchKernelGGL((k_trace_only<COUNT, R, MEDIA, PRIMARY, true, TREE>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A, 0u);
-                hipLaunchKernelGGL((k_classify<COUNT, PRIMARY, true>), grid_classify, block, 0, pipe.stream, r->S, pipe.Q, seg, A);
-            }
-            return;
-        }
         hipLaunchKernelGGL((k_trace<COUNT, R, MEDIA, PRIMARY, false, TREE>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A, give_up);
         if (give_up) hipLaunchKernelGGL((k_trace<COUNT, R, MEDIA, PRIMARY, true, TREE>), grid, block, 0, pipe.stream, r->S, pipe.Q, seg, A, 0u);
     };
     if (!r->wide8) launch(std::integral_constant<int, TREE_4_WIDE>{});
     else if (MEDIA == MEDIA_NONE && !PRIMARY && r->dense) launch(std::integral_constant<int, MEDIA == MEDIA_NONE && !PRIMARY ? TREE_8_WIDE_DENSE : TREE_8_WIDE>{});
     else launch(std::integral_constant<int, TREE_8_WIDE>{});
-    return (give_up ? 2u : 1u) * (r->split ? 2u : 1u);
+    return give_up ? 2u : 1u;
 }
 template <bool COUNT, int MEDIA>
 uint32_t launch_trace_media(v4r_renderer *r, Pipe &pipe, uint32_t seg, const PrimaryArgs &A) {
@@ -2812,6 +2507,28 @@ int v4r_trace_rays(v4r_renderer *r, uint32_t n, const float *host_origin, const 
     if (!r) return set_error(V4R_E_INVALID, "NULL renderer");
     if (n && (!host_origin || !host_dir)) return set_error(V4R_E_INVALID, "NULL ray arrays");
     return trace_common(r, n, host_origin, host_dir, seed, host_prim_id, host_t);
+}
+
+int v4r_tree_read(v4r_renderer *r, v4r_tree_info *info, void *nodes, uint32_t *scene_index, uint32_t *media_direct) {
+    if (!r) return set_error(V4R_E_INVALID, "NULL renderer");
+    std::lock_guard<std::recursive_mutex> hold(r->mu);
+    HIP_TRY(hipSetDevice(r->device));
+    if (info) {
+        std::memset(info, 0, sizeof *info);
+        info->width = r->wide8 ? 8u : 4u;
+        info->n_nodes = r->S.n_nodes == 0 ? 0u : r->n_wide_nodes;
+        info->n_top_nodes = r->S.n_top_nodes;
+        info->n_prims = r->S.n_prims;
+        info->n_media_direct = r->S.n_media_direct;
+        info->media_in_tree = r->media_mode == MEDIA_IN_TREE ? 1u : 0u;
+    }
+    if (nodes && r->S.n_nodes != 0 && r->n_wide_nodes != 0) {
+        HIP_TRY(hipStreamSynchronize(r->stream));
+        HIP_TRY(hipMemcpy(nodes, r->S.nodes4, (size_t)r->n_wide_nodes * 128, hipMemcpyDeviceToHost));
+    }
+    if (scene_index && !r->scene_index.empty()) std::memcpy(scene_index, r->scene_index.data(), r->scene_index.size() * sizeof(uint32_t));
+    if (media_direct && !r->media_direct.empty()) std::memcpy(media_direct, r->media_direct.data(), r->media_direct.size() * sizeof(uint32_t));
+    return V4R_OK;
 }
 
 int v4r_stats_enable(v4r_renderer *r, int on) {

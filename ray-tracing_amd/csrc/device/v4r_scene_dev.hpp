@@ -142,7 +142,10 @@ V4R_DEV bool tri_t(const Prim &pr, V3 o, V3 d, float t_min, float t_max, float &
 
 // TransformHittable::hit prologue, hittable/transform.rs:69-76
 V4R_DEV void to_object(const float *x, V3 &o, V3 &d, float &nrm) {
-    const float *inv = x + 12;
+    // the inverse map's twelve floats as three 16-byte loads (a transform record is 96 bytes in a 256-byte-aligned table)
+    const float4 *q = reinterpret_cast<const float4 *>(x + 12);
+    const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+    const float inv[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
     V3 dir = mat_mul(inv, d);
     nrm = norm(dir);
     o = mat_mul(inv, o) + v3(inv[9], inv[10], inv[11]);

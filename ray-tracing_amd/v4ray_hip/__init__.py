@@ -803,6 +803,20 @@ class Renderer:
         check_dev(device_lib().v4r_profile_read(self._h, C.byref(ms), C.byref(n), int(reset)))
         return float(ms.value), int(n.value)
 
+    def read_tree(self) -> dict:
+        """The tree the kernels traverse (v4r_tree_read): width, nodes as an (n_nodes, 32) uint32 array, the scene index of
+        every device primitive and the constant media tested before the tree."""
+        info = _abi.TreeInfo()
+        check_dev(device_lib().v4r_tree_read(self._h, C.byref(info), None, None, None))
+        nodes = np.zeros((info.n_nodes, 32), dtype=np.uint32)
+        scene_index = np.zeros(info.n_prims, dtype=np.uint32)
+        media_direct = np.zeros(info.n_media_direct, dtype=np.uint32)
+        up = C.POINTER(C.c_uint32)
+        check_dev(device_lib().v4r_tree_read(self._h, None, nodes.ctypes.data_as(C.c_void_p), scene_index.ctypes.data_as(up),
+                                             media_direct.ctypes.data_as(up)))
+        return {"width": int(info.width), "n_top_nodes": int(info.n_top_nodes), "media_in_tree": bool(info.media_in_tree),
+                "nodes": nodes, "scene_index": scene_index, "media_direct": media_direct}
+
     def enable_stats(self, on: bool = True) -> None:
         check_dev(device_lib().v4r_stats_enable(self._h, int(on)))
 

@@ -97,6 +97,11 @@ class Stats(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
+class TreeInfo(C.Structure):  # v4r_tree_info
+    _fields_ = [("width", C.c_uint32), ("n_nodes", C.c_uint32), ("n_top_nodes", C.c_uint32), ("n_prims", C.c_uint32),
+                ("n_media_direct", C.c_uint32), ("media_in_tree", C.c_uint32), ("pad", C.c_uint32 * 2)]
+
+
 class CameraParam(C.Structure):
     _fields_ = [("look_from", C.c_float * 3), ("look_at", C.c_float * 3), ("vfov", C.c_float), ("up", C.c_float * 3),
                 ("aspect_ratio", C.c_float), ("aperture", C.c_float), ("focus_dist", C.c_float),
@@ -185,6 +190,7 @@ DEVICE_SYMBOLS = [
     "v4r_accum_bind", "v4r_reduce", "v4r_accum_clear", "v4r_accum_read", "v4r_accum_write", "v4r_accum_device", "v4r_tonemap_u8",
     "v4r_trace_primary", "v4r_trace_rays", "v4r_stats_enable", "v4r_stats_read", "v4r_synchronize",
     "v4r_stream", "v4r_pass_count", "v4r_profile_enable", "v4r_profile_read", "v4r_profile_read_groups", "v4r_render_noalloc",
+    "v4r_tree_read",
 ]
 
 
@@ -218,6 +224,7 @@ def device_lib():
     _sig(lib.v4r_tonemap_u8, i32, vp, u32, C.POINTER(C.c_uint8))
     _sig(lib.v4r_trace_primary, i32, vp, up, fp)
     _sig(lib.v4r_trace_rays, i32, vp, u32, fp, fp, u64, up, fp)
+    _sig(lib.v4r_tree_read, i32, vp, C.POINTER(TreeInfo), vp, up, up)
     _sig(lib.v4r_stats_enable, i32, vp, i32)
     _sig(lib.v4r_stats_read, i32, vp, C.POINTER(Stats), i32)
     _sig(lib.v4r_synchronize, i32, vp)

@@ -35,6 +35,7 @@ def lib():
     L.v4o_last_error.restype = C.c_char_p
     L.v4o_render.argtypes = [D, u64, u32, u32, u32, FP, i32, u32, i32, C.POINTER(_abi.Stats)]
     L.v4o_trace_primary.argtypes = [D, UP, FP, i32]
+    L.v4o_set_device_tree.argtypes = [C.POINTER(_abi.TreeInfo), C.c_void_p, UP, UP]
     L.v4o_camera_rays.argtypes = [D, u64, u32, i32, FP, FP]
     L.v4o_trace_rays.argtypes = [D, u32, FP, FP, u64, UP, FP, FP, i32]
     L.v4o_hit.argtypes = [D, u32, FP, FP, f32, f32, u32, FP]
@@ -84,6 +85,19 @@ def render(desc, n_passes, seed=0x5EED, first_pass=0, pass_stride=1, threads=0, 
     _check(lib().v4o_render(desc, seed, first_pass, pass_stride, n_passes, accum.ctypes.data_as(FP), threads,
                             pixel_stride, mode, C.byref(st)))
     return accum, st.as_dict()
+
+
+def set_device_tree(tree):
+    """Hand the oracle the tree of a device renderer (Renderer.read_tree()) for mode 4; None clears it."""
+    if tree is None:
+        _check(lib().v4o_set_device_tree(None, None, None, None))
+        return
+    nodes = np.ascontiguousarray(tree["nodes"], dtype=np.uint32)
+    index = np.ascontiguousarray(tree["scene_index"], dtype=np.uint32)
+    media = np.ascontiguousarray(tree["media_direct"], dtype=np.uint32)
+    info = _abi.TreeInfo(width=tree["width"], n_nodes=nodes.shape[0], n_top_nodes=tree["n_top_nodes"], n_prims=index.shape[0],
+                         n_media_direct=media.shape[0], media_in_tree=int(tree["media_in_tree"]))
+    _check(lib().v4o_set_device_tree(C.byref(info), nodes.ctypes.data_as(C.c_void_p), index.ctypes.data_as(UP), media.ctypes.data_as(UP)))
 
 
 def trace_primary(desc, mode=0):
