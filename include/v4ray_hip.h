@@ -244,9 +244,13 @@ int v4r_render(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_t pas
 /* The same for the band of image rows [row0, row0 + n_rows) only (row 0 = top): the tile split of a
  * multi-GPU job, where every GPU renders all passes of its own band and the accumulators (zero
  * outside the band) are summed.  Pixels draw the random streams of their position in the whole
- * image, so bands rendered separately add up to exactly the image v4r_render produces.  The pass
- * count of the accumulator advances only when the band is the whole image.  No counterpart in the
- * reference, whose passes are always full images (src/renderer.rs:321-332). */
+ * image, so under a light pdf that is a function of the ray alone (V4R_FLAG_PLANE_LIGHT_PDF,
+ * V4R_FLAG_BOUNDED_LIGHT_PDF, or a scene without lights) bands rendered separately add up to exactly
+ * the image v4r_render produces.  Under the default packet-statistics rule the rays that end on a
+ * shape are counted within the band, so a shape that straddles bands sees smaller counts than in a
+ * whole pass: the bands then add up to another estimate of the same image (same mean, not the same
+ * bits).  The pass count of the accumulator advances only when the band is the whole image.  No
+ * counterpart in the reference, whose passes are always full images (src/renderer.rs:321-332). */
 int v4r_render_rows(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_t pass_stride, uint32_t n_passes, uint32_t row0,
                     uint32_t n_rows);
 
@@ -275,7 +279,8 @@ int v4r_accum_bind(v4r_renderer *r, float *device_hwc);
 /* Sum the accumulators of all ranks of an RCCL communicator onto rank `root`, in place, on the
  * renderer's stream (after the passes queued so far): one ncclReduce(sum, fp32, H*W*3) over xGMI, the
  * only exchange step of a multi-GPU job.  `rccl_comm` is the caller's ncclComm_t; the library does not
- * link RCCL: it uses the ncclReduce already loaded in the process, else librccl.so.1.  Replaces the
+ * link RCCL: it uses the ncclReduce already loaded in the process, else librccl.so.1, and refuses (V4R_E_UNSUPPORTED) a
+ * library whose ncclGetVersion does not report 2.x, the versions whose ncclFloat32 / ncclSum values it passes.  Replaces the
  * RwLock'd sum of RenderResult::add across the reference's concurrent passes (src/main.rs:56-63,
  * src/renderer.rs:355-368). */
 int v4r_reduce(v4r_renderer *r, void *rccl_comm, int root);

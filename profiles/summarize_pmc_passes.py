@@ -27,9 +27,27 @@ VALU_ISSUE_CYCLES = 2   # a wave64 vector instruction occupies its SIMD's issue 
 SIZES = {"c1": (800, 800), "c2": (1920, 1080), "c3": (1024, 1024), "c4": (1920, 1080), "c5": (3840, 2160)}
 
 
+SHADE_CLASS = {"0": "light", "1": "lambert", "2": "lambert_noise", "3": "metal", "4": "dielectric", "5": "isotropic"}
+
+
 def short(name):
-    k = re.sub(r"\(anonymous namespace\)::", "", name)
-    return re.sub(r"[<(].*", "", k).replace("void ", "")
+    k = re.sub(r"\(anonymous namespace\)::", "", name).replace("void ", "")
+    m = re.match(r"k_shade<(\d)", k)
+    if m:  # one entry per material class: their costs differ by an order of magnitude (Perlin noise)
+        return "k_shade_" + SHADE_CLASS.get(m.group(1), m.group(1))
+    return re.sub(r"[<(].*", "", k)
+
+
+def kernel_sources_sha256():
+    """Hash of the device sources the profiled library was built from; bench.py compares it with the sources it runs."""
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    h = hashlib.sha256()
+    for rel in ("ray-tracing_amd/csrc/device/v4r_device.hip", "ray-tracing_amd/csrc/device/v4r_scene_dev.hpp",
+                "ray-tracing_amd/csrc/device/v4r_math.hpp", "include/v4ray_hip.h"):
+        with open(os.path.join(here, "..", rel), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
 
 
 def totals(pattern):
@@ -62,7 +80,7 @@ ta, _ = totals(os.path.join(root, "pmc2_ta", "*_counter_collection.csv"))
 secs = durations(os.path.join(root, "pmc2_time", "kernel_trace.csv"))
 out = {"command": f"V4R_PIPES=1 rocprofv3 --pmc <one counter set per pass> --output-format csv -- python3 bench.py --workload {workload} "
                   "--steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-side --spp 64   (+ one --kernel-trace pass for the durations)",
-       "workload": f"{workload} {w_}x{h_}, {spp} spp", "paths": paths,
+       "workload": f"{workload} {w_}x{h_}, {spp} spp", "paths": paths, "kernel_sources_sha256": kernel_sources_sha256(),
        "note": "FETCH_SIZE/WRITE_SIZE are KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request, so read bytes = 2 x "
                "FETCH_SIZE x 1024. SQ_*_CYCLES count quad-cycles summed over waves; GRBM_GUI_ACTIVE is summed over the 8 XCDs. "
                "hbm_frac = HBM bytes / exclusive kernel seconds / 8 TB/s. valu_issue_frac = SQ_INSTS_VALU x 2 cycles / "

@@ -2385,13 +2385,27 @@ int v4r_reduce(v4r_renderer *r, void *rccl_comm, int root) {
     std::lock_guard<std::recursive_mutex> hold(r->mu);
     // ncclResult_t ncclReduce(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t)
     using reduce_fn = int (*)(const void *, void *, size_t, int, int, int, void *, hipStream_t);
-    static reduce_fn reduce = [] {
+    using version_fn = int (*)(int *);
+    struct Rccl {
+        reduce_fn reduce = nullptr;
+        int version = 0;  // ncclGetVersion's code; 0: not known
+    };
+    static const Rccl rccl = [] {
+        Rccl f;
+        void *lib = nullptr;
         void *sym = dlsym(RTLD_DEFAULT, "ncclReduce");  // the RCCL the caller's communicator came from, if it is loaded globally
-        if (!sym)
-            if (void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL)) sym = dlsym(lib, "ncclReduce");
-        return (reduce_fn)sym;
+        if (!sym && (lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL))) sym = dlsym(lib, "ncclReduce");
+        f.reduce = (reduce_fn)sym;
+        void *ver = lib ? dlsym(lib, "ncclGetVersion") : dlsym(RTLD_DEFAULT, "ncclGetVersion");
+        if (ver && ((version_fn)ver)(&f.version) != 0) f.version = 0;
+        return f;
     }();
-    if (!reduce) return set_error(V4R_E_UNSUPPORTED, "ncclReduce not found: load RCCL (librccl.so.1) before calling v4r_reduce");
+    if (!rccl.reduce) return set_error(V4R_E_UNSUPPORTED, "ncclReduce not found: load RCCL (librccl.so.1) before calling v4r_reduce");
+    // The two enumerators passed below are written out here (the library does not include rccl.h): ncclFloat32 = 7 and
+    // ncclSum = 0 in every NCCL / RCCL 2.x.  A library that does not report a 2.x version is not called.
+    if (rccl.version < 2000 || rccl.version >= 30000)
+        return set_error(V4R_E_UNSUPPORTED, "v4r_reduce needs an RCCL that reports version 2.x through ncclGetVersion (got code " + std::to_string(rccl.version) + ")");
+    const reduce_fn reduce = rccl.reduce;
     HIP_TRY(hipSetDevice(r->device));
     constexpr int nccl_float32 = 7, nccl_sum = 0;  // rccl.h: ncclFloat32, ncclSum
     int rc = reduce(r->accum, r->accum, (size_t)r->npix * 3, nccl_float32, nccl_sum, root, rccl_comm, r->stream);

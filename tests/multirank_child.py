@@ -48,7 +48,7 @@ def main():
     torch.cuda.synchronize()
     if rank == 0:
         np.save(args.out, accum.cpu().numpy())
-    print(f"rank {rank}: rendered {n} passes", flush=True)
+    print(f"rank {rank}: rendered {n} passes, backend {dist.get_backend()}", flush=True)
     r.close()
     dist.destroy_process_group()
 

@@ -7,6 +7,6 @@ for setting in "$@"; do
   for w in $WL; do
     if [ "$setting" = "-" ]; then envs=""; else envs="$setting"; fi
     env $envs timeout -k 10 300 python bench.py --workload $w --steps 1 --warmup 1 --no-cpu-baseline --no-side --spp $SPP 2>&1 | tail -1 |
-      python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('[$setting]', '$w', d['value'], d['ms_per_step'], d['roofline']['hbm']['trace']['ms_per_64_passes'], d['roofline']['hbm']['shade']['ms_per_64_passes'])" || exit 1
+      python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('[$setting]', '$w', d['value'], d['ms_per_step'], d['roofline']['groups']['trace']['ms_per_64_passes'], d['roofline']['groups']['shade']['ms_per_64_passes'])" || exit 1
   done
 done

@@ -7,6 +7,6 @@ for v in "$@"; do
   for w in $WL; do
     if [ "$v" = base ]; then unset V4R_DEVICE_LIB; else export V4R_DEVICE_LIB="$PWD/ray-tracing_amd/lib/variants/$v.so"; fi
     timeout -k 10 300 python bench.py --workload $w --steps 1 --warmup 1 --no-cpu-baseline --spp $SPP 2>&1 | tail -1 |
-      python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('$v', '$w', d['value'], d['ms_per_step'], d['roofline']['hbm']['trace']['ms_per_64_passes'], d['roofline']['hbm']['shade']['ms_per_64_passes'])" || exit 1
+      python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('$v', '$w', d['value'], d['ms_per_step'], d['roofline']['groups']['trace']['ms_per_64_passes'], d['roofline']['groups']['shade']['ms_per_64_passes'])" || exit 1
   done
 done
