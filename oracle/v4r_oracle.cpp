@@ -117,7 +117,7 @@ enum {
     DIM_TIME = 4,
     DIM_SCATTER = 8,       // 8..13: material / pdf sampling at the end of the segment
     DIM_PACKET_SLOT = 14,  // packet-statistics rule: is the ray in its shape's last, partial packet
-    DIM_PACKET_ANY = 16,   // 16..31: packet-statistics rule, + (light index & 15): does a packet mate hit that light
+    DIM_PACKET_ANY = 16,   // 16..31: packet-statistics rule, + (light index & 15): does a packet mate hit that light (lights_value_stat)
     DIM_MEDIUM = 32   // 32..63: constant-medium free-path draw, + (primitive index & 31)
 };
 
@@ -1011,7 +1011,9 @@ float lights_value_stat(Ctx &ctx, V3 origin, V3 normal, V3 dir, uint32_t li, uin
             float q = 1.0f - (0.5f * (l == li ? 1.0f : 0.0f) + 0.5f * light_cosine_share(s->prims[s->lights[l]], origin, normal));
             float p_none = 1.0f;
             for (uint32_t m = 1; m < k; ++m) p_none = p_none * q;
-            if (!(draw(key, DIM_PACKET_ANY + (l & 15u)) >= p_none)) density = 0.0f;
+            // one draw per light: dimension 16 + (l mod 16) of the segment's stream, for lights beyond the sixteenth of a key derived from it
+            const uint32_t light_key = l < 16u ? key : mix32(key + (l >> 4) * 0x9E3779B9u);
+            if (!(draw(light_key, DIM_PACKET_ANY + (l & 15u)) >= p_none)) density = 0.0f;
         }
         sum += weight * density;
     }

@@ -294,7 +294,7 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
     constexpr bool WIDE8 = TREE != TREE_4_WIDE;
     __shared__ uint2 lds_stack[lds_depth(WIDE8) * BLOCK];
     __shared__ uint32_t s_base;
-    __shared__ uint32_t s_cnt[CLS_COUNT + 1];  // [CLS_COUNT]: rays given up
+    __shared__ uint32_t s_cnt[2][CLS_COUNT + 1];  // per destination ([CLS_COUNT]: rays given up), one set per chunk parity
     __shared__ uint32_t s_where[RAYS_PER_THREAD * BLOCK];  // per ray of the chunk: class << 16 | rank among the chunk's hits of that class
     __shared__ v4f s_top[8 * (WIDE8 ? TOP_NODES_8 : TOP_NODES)];
     StackT<lds_depth(WIDE8)> st;
@@ -318,7 +318,6 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
     TraceCounters cnt;
     uint32_t n_traced = 0, n_lights = 0;
     constexpr uint32_t DEST_NONE = 0xFFu;
-    bool started = false;
     // A short queue is spread over as many workgroups as possible: a thread then traces fewer rays per
     // chunk (down to one), so the launch lasts about one ray's traversal instead of RAYS_PER_THREAD.
     const uint32_t per_thread = min((uint32_t)RAYS_PER_THREAD, max(1u, (n_in + gridDim.x * BLOCK - 1u) / (gridDim.x * BLOCK)));
@@ -327,15 +326,19 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
     unsigned long long clk_fetch = 0, clk_end = 0, clk_chunk = 0, clk_traverse = 0, wave_rays = 0;
     const unsigned long long clk_start = COUNT ? phase_clock() : 0ull;
 #endif
+    // The chunk's bookkeeping costs two barriers and one trip to the global counters: when the chunk's rays are done, the
+    // first threads add its counts to the segment's (one atomic per destination) while another takes the next chunk from
+    // the cursor; after the second barrier every thread writes its rays' queue entries and goes on with the next chunk.
+    // The counts of consecutive chunks live in two sets, so that the next chunk's set is cleared between the barriers
+    // of this one and a fast wave cannot rank into a set that is still being read.
+    if (threadIdx.x == 0) s_base = blockIdx.x * chunk;
+    if (threadIdx.x <= CLS_COUNT) s_cnt[0][threadIdx.x] = 0;
+    uint32_t parity = 0;
+    __syncthreads();
     while (true) {
 #ifdef V4R_PHASE_CLOCKS
         unsigned long long tc = COUNT ? phase_clock() : 0ull;
 #endif
-        if (threadIdx.x == 0)
-            s_base = started ? gridDim.x * chunk + atomicAdd(second ? &ctr->second_cursor : &ctr->trace_cursor, chunk) : blockIdx.x * chunk;
-        if (threadIdx.x <= CLS_COUNT) s_cnt[threadIdx.x] = 0;
-        started = true;
-        __syncthreads();
         const uint32_t base = s_base;
         if (base >= n_in) break;
 #ifdef V4R_PHASE_CLOCKS
@@ -407,6 +410,15 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
                 asm volatile("" : "+v"(i));
                 // what becomes of the ray: the queue it goes to (a shading class, or CLS_COUNT = given up), or none (its path ended)
                 uint32_t dest = DEST_NONE;
+                // Everything the end of a ray may need goes out in one burst of loads, before any of it is looked at: the
+                // class word of the primitive hit and the rest of the ray's record (path slot, throughput).  A wave holds
+                // rays that end in every possible way, so it would otherwise wait for one trip to memory per way, one after the other.
+                uint32_t info = 0u;
+                float4 bb = make_float4(0, 0, 0, 0), cc = bb;
+                if (active && !gave_up) {
+                    if (best.prim != NO_PRIM) info = S.prim_info[best.prim];
+                    if (!PRIMARY) bb = rq[1][i], cc = rq[2][i];
+                }
                 if (active && gave_up) {
                     Q.hitd[i] = make_float4(best.t, __uint_as_float(best.prim), best.u, best.v);
                     dest = (uint32_t)CLS_COUNT;
@@ -419,13 +431,11 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
                         // handful of addresses -- every launch anew, until each compute unit has seen the flag; from that
                         // count on the rule treats every packet as full).  The flag is read and written with plain
                         // accesses: a stale 0 only costs one more increment.  Shapes full in every pass (build()) skip all of it.
-                        const uint32_t info = S.prim_info[best.prim], cls = info >> 24;
+                        const uint32_t cls = info >> 24;
                         uint32_t *n_rays = Q.shape_rays;
                         uint32_t full = 1u;
                         if (count_shape_rays && !(info & PRIM_INFO_ALWAYS_FULL)) {  // (a shape full in every pass is not counted at all)
-                            // (the path slot, which gives the pass, is read here and not with the direction: a register carried
-                            // through the traversal costs more than this load, which only rays that end on a counted shape make)
-                            if (!PRIMARY) slot = __float_as_uint(rq[1][i].z);
+                            if (!PRIMARY) slot = __float_as_uint(bb.z);
                             uint32_t pass = PRIMARY ? pass_in_batch : pass_of_slot(slot, npix, A.inv_npix);
                             if (V4R_CHECK(Q.stats + 8, CHECK_RAY_COUNTER, (size_t)(pass + 1u) * S.n_prims <= Q.flags_offset)) {
                                 n_rays += (size_t)pass * S.n_prims + best.prim;
@@ -445,8 +455,7 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
                             if (PRIMARY) {
                                 Q.rad[pass_in_batch * npix + pixel] = make_float4(1.0f * e.x, 1.0f * e.y, 1.0f * e.z, 0.0f);
                             } else {
-                                float4 bb = rq[1][i], c = rq[2][i];
-                                Q.rad[__float_as_uint(bb.z)] = make_float4(bb.w * e.x, c.x * e.y, c.y * e.z, 0.0f);
+                                Q.rad[__float_as_uint(bb.z)] = make_float4(bb.w * e.x, cc.x * e.y, cc.y * e.z, 0.0f);
                             }
                             if (COUNT) n_lights++;
                         } else {
@@ -474,8 +483,7 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
                     } else if (PRIMARY) {  // renderer.rs:184: a miss takes the background colour
                         Q.rad[pass_in_batch * npix + pixel] = make_float4(S.bg[0], S.bg[1], S.bg[2], 0.0f);
                     } else {
-                        float4 bb = rq[1][i], c = rq[2][i];
-                        Q.rad[__float_as_uint(bb.z)] = make_float4(bb.w * S.bg[0], c.x * S.bg[1], c.y * S.bg[2], 0.0f);
+                        Q.rad[__float_as_uint(bb.z)] = make_float4(bb.w * S.bg[0], cc.x * S.bg[1], cc.y * S.bg[2], 0.0f);
                     }
                 }
                 // Rank of the ray among the chunk's rays with the same destination: the lanes of the wave that share a
@@ -487,7 +495,7 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
                     const uint32_t which = (uint32_t)__shfl((int)dest, leader, 64);
                     const unsigned long long same = __ballot(dest == which);
                     uint32_t first = 0u;
-                    if ((int)lane_id() == leader) first = atomicAdd(&s_cnt[which], (uint32_t)__popcll(same));
+                    if ((int)lane_id() == leader) first = atomicAdd(&s_cnt[parity][which], (uint32_t)__popcll(same));
                     first = (uint32_t)__shfl((int)first, leader, 64);
                     if (dest == which) w = (which << 16) | (first + (uint32_t)__popcll(same & ((1ull << lane_id()) - 1ull)));
                     todo &= ~same;
@@ -503,9 +511,12 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
 #endif
         __syncthreads();
         if (threadIdx.x <= CLS_COUNT) {
-            uint32_t n = s_cnt[threadIdx.x];
+            uint32_t n = s_cnt[parity][threadIdx.x];
             uint32_t *total = threadIdx.x < CLS_COUNT ? &ctr->hit_count[threadIdx.x] : &ctr->given_up;
-            s_cnt[threadIdx.x] = n ? atomicAdd(total, n) : 0u;
+            s_cnt[parity][threadIdx.x] = n ? atomicAdd(total, n) : 0u;
+            s_cnt[parity ^ 1u][threadIdx.x] = 0u;
+        } else if (threadIdx.x == CLS_COUNT + 1) {
+            s_base = gridDim.x * chunk + atomicAdd(second ? &ctr->second_cursor : &ctr->trace_cursor, chunk);
         }
         __syncthreads();
 #pragma unroll 1
@@ -514,11 +525,11 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
             uint32_t w = pos < n_in ? s_where[j * BLOCK + threadIdx.x] : 0xFFFFFFFFu;  // slots past the queue end were never traced
             if (w != 0xFFFFFFFFu) {
                 uint32_t i = second ? Q.given_up[pos] : pos;
-                uint32_t k = w >> 16, idx = s_cnt[k] + (w & 0xFFFFu);
+                uint32_t k = w >> 16, idx = s_cnt[parity][k] + (w & 0xFFFFu);
                 if (V4R_CHECK(Q.stats + 8, CHECK_QUEUE_INDEX, idx < Q.cap && i < Q.cap)) (k < (uint32_t)CLS_COUNT ? Q.hit[k] : Q.given_up)[idx] = i;
             }
         }
-        __syncthreads();
+        parity ^= 1u;
 #ifdef V4R_PHASE_CLOCKS
         if (COUNT) clk_chunk += phase_clock() - tc;
 #endif
@@ -1001,6 +1012,7 @@ struct v4r_renderer {
     std::vector<uint32_t> media_direct;    // constant media tested before the tree (device numbering)
     unsigned char *scratch_ptr = nullptr;  // this device's copy of `scratch`
     Pipe noalloc;                          // queues carved out of it (Q.cap = 0: the scene does not fit), on the public stream
+    std::string noalloc_why;               // what did not fit, when Q.cap = 0
 
     template <class T>
     int alloc(T **out, size_t count) {
@@ -1653,10 +1665,23 @@ void carve_noalloc(v4r_renderer *r, int n_cu) {
     };
     Q.spill_stride = (size_t)pipe.grid_trace * BLOCK;
     Q.spill_depth = r->spill_depth;
-    if (!take(&Q.spill, Q.spill_stride * std::max(r->spill_depth, 1u))) return;
-    if (!take(&Q.ctr, (size_t)r->max_depth + 1)) return;
+    auto mib = [](size_t bytes) { return std::to_string((bytes + (1u << 20) - 1) >> 20) + " MiB"; };
+    const size_t spill_bytes = Q.spill_stride * std::max(r->spill_depth, 1u) * sizeof(uint2), ctr_bytes = ((size_t)r->max_depth + 1) * sizeof(SegCtr);
+    if (!take(&Q.spill, Q.spill_stride * std::max(r->spill_depth, 1u))) {
+        r->noalloc_why = "the traversal-stack spill slab of this scene's tree (" + mib(spill_bytes) + ") does not fit";
+        return;
+    }
+    if (!take(&Q.ctr, (size_t)r->max_depth + 1)) {
+        r->noalloc_why = "the segment counters of a depth budget of " + std::to_string(r->max_depth) + " (" + mib(ctr_bytes) + ") do not fit";
+        return;
+    }
     if (r->S.packet_rule) {  // ray counters of the packet-statistics rule, for batches of up to NOALLOC_COUNTED_PASSES passes
-        if (!take(&Q.shape_rays, 2 * (size_t)NOALLOC_COUNTED_PASSES * r->S.n_prims)) return;
+        if (!take(&Q.shape_rays, 2 * (size_t)NOALLOC_COUNTED_PASSES * r->S.n_prims)) {
+            r->noalloc_why = "the per-shape ray counters of the light pdf (" + std::to_string(NOALLOC_COUNTED_PASSES) + " passes x " + std::to_string(r->S.n_prims) +
+                             " primitives x 8 bytes = " + mib(2 * (size_t)NOALLOC_COUNTED_PASSES * r->S.n_prims * sizeof(uint32_t)) +
+                             ") do not fit: the scene has too many primitives (V4R_FLAG_PLANE_LIGHT_PDF or V4R_FLAG_BOUNDED_LIGHT_PDF need no counters)";
+            return;
+        }
         pipe.count_passes = NOALLOC_COUNTED_PASSES;
     }
     // per path slot: two ray queues of three 16-byte columns, the hit record, the radiance slot, the given-up index
@@ -1664,7 +1689,10 @@ void carve_noalloc(v4r_renderer *r, int n_cu) {
     const size_t per_slot = 2 * 3 * sizeof(float4) + 2 * sizeof(float4) + (1 + CLS_COUNT) * sizeof(uint32_t);
     size_t cap = ((size_t)V4R_NOALLOC_SCRATCH_BYTES - off) / per_slot;
     cap = cap > 4096 ? (cap - 4096) & ~(size_t)63 : 0;  // room for the 256-byte alignment of each of the 15 arrays
-    if (cap == 0) return;
+    if (cap == 0) {
+        r->noalloc_why = "the spill slab (" + mib(spill_bytes) + "), segment counters and ray counters leave no room for path slots";
+        return;
+    }
     bool ok = true;
     for (int p = 0; p < 2; ++p)
         for (int c = 0; c < 3; ++c) ok = ok && take(&Q.ray[p][c], cap);
@@ -1859,12 +1887,23 @@ int build(v4r_renderer *r, const v4r_scene_desc *given, uint32_t bvh_depth) {
         const uint32_t depth_max = std::max(wide_depth, wide_depth8) + 1u;
         constexpr uint32_t in_lds = (uint32_t)std::min(lds_depth(false), lds_depth(true));  // one slab for both trees' runs
         const size_t spill = depth_max > in_lds ? depth_max - in_lds : 0;
-        uint2 *slab = nullptr;
-        uint32_t *d_prim = nullptr;
-        float *d_t = nullptr;
-        HIP_TRY(hipMalloc((void **)&slab, std::max<size_t>(256, spill * grid * BLOCK * sizeof(uint2))));
-        HIP_TRY(hipMalloc((void **)&d_prim, (size_t)r->npix * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc((void **)&d_t, (size_t)r->npix * sizeof(float)));
+        // (freed on every way out of this block, the early error returns included)
+        struct Temporaries {
+            uint2 *slab = nullptr;
+            uint32_t *d_prim = nullptr;
+            float *d_t = nullptr;
+            ~Temporaries() {
+                (void)hipFree(slab);
+                (void)hipFree(d_prim);
+                (void)hipFree(d_t);
+            }
+        } tmp;
+        HIP_TRY(hipMalloc((void **)&tmp.slab, std::max<size_t>(256, spill * grid * BLOCK * sizeof(uint2))));
+        HIP_TRY(hipMalloc((void **)&tmp.d_prim, (size_t)r->npix * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **)&tmp.d_t, (size_t)r->npix * sizeof(float)));
+        uint2 *slab = tmp.slab;
+        uint32_t *d_prim = tmp.d_prim;
+        float *d_t = tmp.d_t;
         Queues Q{};
         Q.spill = slab;
         Q.spill_stride = (size_t)grid * BLOCK;
@@ -1888,9 +1927,6 @@ int build(v4r_renderer *r, const v4r_scene_desc *given, uint32_t bvh_depth) {
             HIP_TRY(hipMemcpy(work[w8], r->stats, sizeof work[w8], hipMemcpyDeviceToHost));
             HIP_TRY(hipMemset(r->stats, 0, 128));
         }
-        (void)hipFree(slab);
-        (void)hipFree(d_prim);
-        (void)hipFree(d_t);
         const double cost4 = (double)work[0][6] + WIDE_LEAF_COST * (double)work[0][7], cost8 = WIDE8_STEP_COST * (double)work[1][6] + WIDE_LEAF_COST * (double)work[1][7];
         r->wide8 = cost8 < cost4;
         if (const char *env = std::getenv("V4R_WIDE")) r->wide8 = std::atoi(env) == 8;
@@ -2210,6 +2246,9 @@ int run_batch(v4r_renderer *r, Pipe &pipe, uint64_t seed, uint32_t first_pass, u
 // Checked build: wait for the job and turn failed device-side bounds checks into an error.
 int report_checks(v4r_renderer *r) {
 #ifdef V4R_DEBUG_CHECKS
+    // (a stream that is being captured into a graph cannot be waited for: the checks are then read by the next call outside a capture)
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(r->stream, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone) return V4R_OK;
     HIP_TRY(hipStreamSynchronize(r->stream));
     unsigned long long failed = 0;
     HIP_TRY(hipMemcpy(&failed, r->stats + 8, sizeof failed, hipMemcpyDeviceToHost));
@@ -2349,8 +2388,8 @@ int v4r_render_noalloc(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint
     std::lock_guard<std::recursive_mutex> hold(r->mu);
     Pipe &pipe = r->noalloc;
     if (pipe.Q.cap == 0)
-        return set_error(V4R_E_LIMIT, "v4r_render_noalloc: the scene's traversal stack and depth budget leave no room for path slots in the " +
-                                          std::to_string(V4R_NOALLOC_SCRATCH_BYTES >> 20) + " MiB scratch");
+        return set_error(V4R_E_LIMIT, "v4r_render_noalloc: in the " + std::to_string(V4R_NOALLOC_SCRATCH_BYTES >> 20) + " MiB scratch, " +
+                                          (r->noalloc_why.empty() ? std::string("no room is left for path slots") : r->noalloc_why));
     if (r->npix > pipe.Q.cap)
         return set_error(V4R_E_LIMIT, "v4r_render_noalloc: one pass of " + std::to_string(r->S.width) + " x " + std::to_string(r->S.height) + " = " +
                                           std::to_string(r->npix) + " paths exceeds the " + std::to_string(pipe.Q.cap) +

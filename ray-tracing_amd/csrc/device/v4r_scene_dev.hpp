@@ -1003,7 +1003,10 @@ V4R_DEV float lights_value(const SceneDev &S, V3 origin, V3 normal, V3 dir, uint
                 float q = 1.0f - (0.5f * (l == li ? 1.0f : 0.0f) + 0.5f * light_cosine_share(pr, origin, normal));
                 float p_none = 1.0f;
                 for (uint32_t m = 1u; m < k; ++m) p_none = p_none * q;
-                if (!(draw(key, DIM_PACKET_ANY + (l & 15u)) >= p_none)) density = 0.0f;
+                // one draw per light: dimension 16 + (l mod 16) of the segment's stream, for lights beyond the sixteenth of a
+                // key derived from it (lights l and l + 16 would otherwise share their draw)
+                const uint32_t light_key = l < 16u ? key : mix32(key + (l >> 4) * 0x9E3779B9u);
+                if (!(draw(light_key, DIM_PACKET_ANY + (l & 15u)) >= p_none)) density = 0.0f;
             }
         }
         sum += weight * density;

@@ -586,8 +586,133 @@ class Scene:
 class Renderer:
     """PyRenderer, src/renderer.rs:430-477.
 
-    `await renderer.render()` yields one 1-spp pass as an (H, W, 3) float32 array, as the reference
-    does; callers accumulate passes themselves (main.py:759-769).  `render_passes` keeps the sum on
+    `await renderer.render()` yields one distinct 1-spp pass as an (H, W, 3) float32 array, as the reference
+    does; callers accumulate passes themselves (main.py:759-769).  `render(shared=True)` lets the calls in
+    flight share one device job (for callers that only sum).  `render_passes` keeps the sum on
+    the device instead, which is what the benchmark and the CLI use.
+    """
+
+    def __init__(self, param: RendererParam, camera: PerspectiveCameraParam, scene: Scene, device: int = 0,
+                 seed: int = 0x5EED):
+        self.param, self.camera, self.scene = param, camera, scene
+        self.width, self.height = param.width, param.height
+        self.seed = int(seed)
+        self._next_pass = 0
+        self._lock = threading.Lock()  # render() may run on several executor threads at once (main.py:1986-1990)
+        self._pending, self._pending_lock, self._draining = [], threading.Lock(), False  # render() calls waiting for a batch
+        self._desc = scene.flatten(param, camera)
+        lib = device_lib()
+        h = C.c_void_p()
+        check_dev(lib.v4r_renderer_create(self._desc, int(device), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        # (waits for a render() batch in flight: the handle must not be destroyed under the executor thread that is using it)
+        lock = getattr(self, "_lock", None)
+        if lock is None:
+            return
+        with lock:
+            h, self._h = getattr(self, "_h", None), None
+            if h:
+                device_lib().v4r_renderer_destroy(h)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                host_lib().v4rh_scene_free(h)
+            except Exception:
+                pass
+
+    @classmethod
+    def from_json(cls, path, perlin_seed: int = 1) -> "Scene":
+        """serde_json::from_reader + build_scene (src/main.rs:31-34); also reads the renderer and camera blocks."""
+        h = C.c_void_p()
+        check_host(host_lib().v4rh_scene_load_json_file(os.fspath(path).encode(), perlin_seed, C.byref(h)))
+        return cls._adopt(h)
+
+    @classmethod
+    def from_json_text(cls, text: str, base_dir: str = "", perlin_seed: int = 1) -> "Scene":
+        h = C.c_void_p()
+        check_host(host_lib().v4rh_scene_load_json_text(text.encode(), base_dir.encode(), perlin_seed, C.byref(h)))
+        return cls._adopt(h)
+
+    @classmethod
+    def _adopt(cls, h):
+        s = cls((0, 0, 0), _handle=h)
+        lib = host_lib()
+        rp, cp = _abi.RendererParamC(), _abi.CameraParam()
+        check_host(lib.v4rh_scene_get_renderer(h, C.byref(rp)))
+        check_host(lib.v4rh_scene_get_camera(h, C.byref(cp)))
+        s._renderer_param = RendererParam._from_c(rp)
+        s._camera_param = PerspectiveCameraParam._from_c(cp)
+        return s
+
+    @property
+    def renderer_param(self) -> Optional[RendererParam]:
+        return self._renderer_param
+
+    @property
+    def camera_param(self) -> Optional[PerspectiveCameraParam]:
+        return self._camera_param
+
+    def _texture_id(self, tex: _Texture) -> int:
+        if not isinstance(tex, _Texture):
+            raise TypeError("expected a v4ray texture")
+        key = id(tex)
+        if key not in self._tex_ids:
+            self._tex_ids[key] = (tex._realize(self), tex)
+        return self._tex_ids[key][0]
+
+    def _material_id(self, mat: _Material) -> int:
+        if not isinstance(mat, _Material):
+            raise TypeError("expected a v4ray material")
+        key = id(mat)
+        if key not in self._mat_ids:
+            self._mat_ids[key] = (mat._realize(self), mat)
+        return self._mat_ids[key][0]
+
+    def add(self, shape: _Shape, material: _Material, important: bool = False) -> None:
+        """Scene::add (src/scene.rs:38-41); important=True is Scene::add_important (:52-61)."""
+        if not isinstance(shape, _Shape):
+            raise TypeError("expected a v4ray shape")
+        lib = host_lib()
+        mat = self._material_id(material)
+        h = shape._handle()
+        try:
+            check_host(lib.v4rh_scene_add(self._h, h, mat, int(bool(important))))
+        finally:
+            lib.v4rh_shape_free(h)
+
+    def __len__(self):
+        return host_lib().v4rh_scene_len(self._h)
+
+    def set_options(self, pretransform_triangles: bool = False, flags: int = 0) -> None:
+        check_host(host_lib().v4rh_scene_set_options(self._h, int(pretransform_triangles), flags))
+
+    def bounding_box(self, index: int) -> AABB:
+        out = (C.c_float * 6)()
+        check_host(host_lib().v4rh_scene_bounding_box(self._h, index, out))
+        return AABB(tuple(out[0:3]), tuple(out[3:6]))
+
+    def flatten(self, param: RendererParam, camera: PerspectiveCameraParam):
+        """Build the BVH and return a pointer to the flat v4r_scene_desc (owned by this scene)."""
+        lib = host_lib()
+        rp, cp = param._to_c(), camera._to_c()
+        check_host(lib.v4rh_scene_set_renderer(self._h, C.byref(rp)))
+        check_host(lib.v4rh_scene_set_camera(self._h, C.byref(cp)))
+        desc = C.POINTER(_abi.SceneDesc)()
+        check_host(lib.v4rh_scene_flatten(self._h, C.byref(desc)))
+        return desc
+
+
+# ---- Renderer --------------------------------------------------------------------------------------
+class Renderer:
+    """PyRenderer, src/renderer.rs:430-477.
+
+    `await renderer.render()` yields one distinct 1-spp pass as an (H, W, 3) float32 array, as the reference
+    does; callers accumulate passes themselves (main.py:759-769).  `render(shared=True)` lets the calls in
+    flight share one device job (for callers that only sum).  `render_passes` keeps the sum on
     the device instead, which is what the benchmark and the CLI use.
     """
 
@@ -625,6 +750,8 @@ class Renderer:
         """One 1-spp pass (Renderer::render, src/renderer.rs:321-332) as (H, W, 3) float32."""
         lib = device_lib()
         with self._lock:  # clear + render + read is one unit: concurrent callers take turns, like the RwLock of renderer.rs:359
+            if not self._h:
+                raise V4RayError("the renderer is closed")
             if pass_index is None:
                 pass_index = self._next_pass
                 self._next_pass += 1
@@ -632,16 +759,21 @@ class Renderer:
             check_dev(lib.v4r_render(self._h, self.seed, int(pass_index), 1, 1))
             return self.read_accumulator()[0]
 
-    async def render(self) -> np.ndarray:
-        """One pass, awaited (PyRenderer.render, src/renderer.rs:462-476).  Calls in flight at the same time (main.py:1986-1990
-        keeps os.cpu_count() of them going) are served by one batch: n waiting callers -> n consecutive passes rendered in one
-        device job and read back once, and each caller gets that batch's mean pass (one shared read-only array when n > 1).
-        Summed over the callers this is the sum of n distinct passes, which is all the reference's callers do with the
-        results (RenderResult.add, renderer.rs:379-386); a lone caller gets its own single pass, as before."""
+    async def render(self, shared: bool = False) -> np.ndarray:
+        """One pass, awaited (PyRenderer.render, src/renderer.rs:450-476): every call returns its own, distinct 1-spp pass
+        as a fresh writable (H, W, 3) float32 array, as the reference does; calls in flight at the same time (main.py:1986-1990
+        keeps os.cpu_count() of them going) take consecutive pass indices and are served one after the other.
+
+        shared=True is the fast path for callers that only add the results up, which is all the reference's own callers do
+        (State.with_render_result, main.py:759-769; RenderResult.add, renderer.rs:355-368): the n calls waiting at the same
+        time are served by ONE device job of n consecutive passes, read back once, and each gets that job's mean pass (one
+        read-only array shared by the n callers).  Their sum is the sum of n distinct passes; the individual images are not
+        independent samples, so a caller that estimates variance from them, shows single passes or edits them in place
+        must not ask for it."""
         loop = asyncio.get_running_loop()
         fut = loop.create_future()
         with self._pending_lock:
-            self._pending.append((loop, fut))
+            self._pending.append((loop, fut, bool(shared)))
             start = not self._draining
             self._draining = True
         if start:
@@ -649,7 +781,8 @@ class Renderer:
         return await fut
 
     def _drain(self) -> None:
-        """Executor thread: serve the waiting render() calls, one batch per round, until none is left."""
+        """Executor thread: serve the waiting render() calls until none is left -- the shared ones of a round by one batch,
+        the others by a pass each."""
         def deliver(fut, img, err):
             if fut.done():  # cancelled meanwhile
                 return
@@ -658,26 +791,51 @@ class Renderer:
             else:
                 fut.set_exception(err)
 
-        while True:
-            with self._pending_lock:
-                batch, self._pending = self._pending, []
-                if not batch:
-                    self._draining = False
-                    return
-            img, err = None, None
+        def hand(loop, fut, img, err):
             try:
-                img = self._render_mean(len(batch))
-            except Exception as e:  # handed to every waiter of the batch
-                err = e
-            for loop, fut in batch:
-                try:
-                    loop.call_soon_threadsafe(deliver, fut, img, err)
-                except RuntimeError:  # that caller's loop has closed
-                    pass
+                loop.call_soon_threadsafe(deliver, fut, img, err)
+            except RuntimeError:  # that caller's loop has closed
+                pass
+
+        batch = []
+        try:
+            while True:
+                with self._pending_lock:
+                    batch, self._pending = self._pending, []
+                    if not batch:
+                        self._draining = False
+                        return
+                together = [(loop, fut) for loop, fut, shared in batch if shared]
+                if together:
+                    img, err = None, None
+                    try:
+                        img = self._render_mean(len(together))
+                    except Exception as e:  # handed to every waiter of the batch
+                        err = e
+                    for loop, fut in together:
+                        hand(loop, fut, img, err)
+                for loop, fut, shared in batch:
+                    if shared:
+                        continue
+                    img, err = None, None
+                    try:
+                        img = self.render_pass()
+                    except Exception as e:
+                        err = e
+                    hand(loop, fut, img, err)
+        except BaseException as e:  # never leave the flag standing: the next render() call must start a new drain
+            with self._pending_lock:
+                left, self._pending = self._pending, []
+                self._draining = False
+            for loop, fut, _ in batch + left:  # (calls already answered ignore it)
+                hand(loop, fut, None, e if isinstance(e, Exception) else RuntimeError("render() interrupted"))
+            raise
 
     def _render_mean(self, n: int) -> np.ndarray:
         lib = device_lib()
         with self._lock:
+            if not self._h:
+                raise V4RayError("the renderer is closed")
             first = self._next_pass
             self._next_pass += n
             check_dev(lib.v4r_accum_clear(self._h))

@@ -143,12 +143,13 @@ def test_reference_front_end_builds_its_objects_against_this_package():
     assert desc.contents.n_prims == 3 and desc.contents.width == 64
 
 
-def _bare_renderer(render_mean):
+def _bare_renderer(render_mean, render_pass=None):
     """A Renderer without a device behind it: only the bookkeeping of the awaited render() calls."""
     import threading
     r = v4ray_hip.Renderer.__new__(v4ray_hip.Renderer)
     r._pending, r._pending_lock, r._draining = [], threading.Lock(), False
     r._render_mean = render_mean
+    r.render_pass = render_pass or (lambda: render_mean(1))
     r._h = None
     return r
 
@@ -169,7 +170,7 @@ def test_awaited_render_calls_are_served_in_batches():
 
     async def worker(k, out):
         for _ in range(5):
-            out.append(await r.render())
+            out.append(await r.render(shared=True))
 
     async def run():
         out = []
@@ -182,6 +183,54 @@ def test_awaited_render_calls_are_served_in_batches():
     assert r._pending == [] and r._draining is False
 
 
+def test_awaited_render_calls_get_distinct_passes_by_default():
+    """Without shared=True every awaited call is a pass of its own (src/renderer.rs:450-476 returns one image per call),
+    whatever else is in flight; shared and distinct calls may be mixed."""
+    import asyncio
+    served = []
+
+    def render_pass():
+        served.append(len(served))
+        return np.full((2, 3, 3), float(served[-1]), dtype=np.float32)
+
+    def render_mean(n):
+        return np.full((2, 3, 3), -float(n), dtype=np.float32)
+
+    r = _bare_renderer(render_mean, render_pass)
+
+    async def run():
+        return await asyncio.gather(*([r.render() for _ in range(6)] + [r.render(shared=True) for _ in range(3)]))
+
+    got = asyncio.run(run())
+    distinct = sorted(float(g[0, 0, 0]) for g in got[:6])
+    assert distinct == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0]      # six calls, six different passes
+    assert all(float(g[0, 0, 0]) < 0 for g in got[6:])       # the shared ones came from batch jobs
+    assert r._draining is False
+
+
+def test_a_failing_drain_does_not_block_later_render_calls():
+    """An exception that is not an Exception subclass (e.g. KeyboardInterrupt in the executor thread) must not leave the
+    drain flag standing: later calls start a new drain."""
+    import asyncio
+    calls = []
+
+    def render_mean(n):
+        calls.append(n)
+        if len(calls) == 1:
+            raise KeyboardInterrupt()
+        return np.zeros((2, 3, 3), dtype=np.float32)
+
+    r = _bare_renderer(render_mean)
+
+    async def one():
+        return await asyncio.wait_for(r.render(shared=True), timeout=5)
+
+    with pytest.raises(BaseException):
+        asyncio.run(one())
+    assert r._draining is False and r._pending == []
+    assert asyncio.run(one()).shape == (2, 3, 3)
+
+
 def test_awaited_render_calls_all_see_a_failure():
     import asyncio
 
@@ -191,8 +240,8 @@ def test_awaited_render_calls_all_see_a_failure():
     r = _bare_renderer(render_mean)
 
     async def run():
-        return await asyncio.gather(*[r.render() for _ in range(4)], return_exceptions=True)
+        return await asyncio.gather(*([r.render(shared=True) for _ in range(4)] + [r.render() for _ in range(2)]), return_exceptions=True)
 
     got = asyncio.run(run())
-    assert len(got) == 4 and all(isinstance(e, v4ray_hip.V4RayError) for e in got)
+    assert len(got) == 6 and all(isinstance(e, v4ray_hip.V4RayError) for e in got)
     assert r._draining is False

@@ -692,16 +692,35 @@ def test_concurrent_render_calls_take_turns():
     r.close()
 
 
+def test_awaited_render_calls_return_distinct_passes():
+    """`await renderer.render()` (main.py:1986-1990 keeps os.cpu_count() in flight): every call returns a pass of its own,
+    bit-identical to that pass rendered alone, as PyRenderer.render does (src/renderer.rs:450-476)."""
+    import asyncio
+    scene, r = make("c3")
+    singles = [r.render_pass(k) for k in range(8)]
+
+    async def many(n):
+        return await asyncio.gather(*[r.render() for _ in range(n)])
+    r._next_pass = 0
+    got = asyncio.run(many(8))
+    assert r._next_pass == 8 and len(got) == 8
+    unused = list(range(8))
+    for g in got:  # (the order in which the calls are served is not specified)
+        match = [k for k in unused if np.array_equal(g, singles[k])]
+        assert len(match) == 1 and g.flags.writeable
+        unused.remove(match[0])
+    r.close()
+
+
 def test_awaited_render_calls_share_batches():
-    """`await renderer.render()` (main.py:1986-1990 keeps os.cpu_count() in flight): calls waiting at the same time are
-    served by one batch and get its mean pass, so their sum is the sum of as many distinct passes; a lone call gets
-    exactly the single pass."""
+    """render(shared=True): calls waiting at the same time are served by one batch and get its mean pass, so their sum is
+    the sum of as many distinct passes; a lone call gets exactly the single pass."""
     import asyncio
     scene, r = make("c3")
     singles = [r.render_pass(k) for k in range(12)]
 
     async def many(n):
-        return await asyncio.gather(*[r.render() for _ in range(n)])
+        return await asyncio.gather(*[r.render(shared=True) for _ in range(n)])
     r._next_pass = 0
     got = asyncio.run(many(8))
     assert r._next_pass == 8 and len(got) == 8
@@ -718,6 +737,8 @@ def test_awaited_render_calls_share_batches():
     assert r._next_pass == 12
     assert np.allclose(total, np.sum(singles, axis=0, dtype=np.float64), rtol=1e-5, atol=1e-5)
     r.close()
+    with pytest.raises(Exception):
+        asyncio.run(many(1))   # a closed renderer refuses, it does not crash
 
 
 def test_row_bands_add_up_to_the_full_image():

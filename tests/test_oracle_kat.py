@@ -583,3 +583,31 @@ def test_random_streams_are_uniform_and_keyed():
     assert 0 <= u.min() and u.max() < 1 and abs(u.mean() - 0.5) < 0.02 and abs(u.var() - 1 / 12) < 0.01
     assert L.v4o_rng_segment_key(1, 2, 3, 4) == L.v4o_rng_segment_key(1, 2, 3, 4)
     assert L.v4o_rng_segment_key(1, 2, 3, 4) != L.v4o_rng_segment_key(2, 2, 3, 4)
+
+
+def test_packet_statistics_rule_with_many_triangle_lights():
+    """A mesh emitter: 32 triangle lights (more than the 16 draw dimensions of the packet-statistics rule, so lights l and
+    l + 16 draw from different keys).  The rule (mode 3) must keep the mean of the reference's own packets (mode 2:
+    aa_rect.rs:158-179 / triangle.rs:110-131 applied per 8-lane packet, one light index per packet, group.rs:91-95)."""
+    s = Scene((0, 0, 0))
+    white = Lambertian(SolidColor((0.7, 0.7, 0.7)))
+    s.add(ZXRect(-8, 8, -8, 8, 0.0, True), white)            # floor
+    s.add(XYRect(-8, 8, 0, 8, 8.0, False), white)            # back wall
+    glow = DiffuseLight(SolidColor((6, 6, 6)))
+    n = 0
+    for i in range(4):                                       # a 4 x 4 grid of quads, two downward-facing triangles each, at y = 6
+        for j in range(4):
+            x0, z0 = -2.0 + i, -2.0 + j
+            a, b, c, d = (x0, 6, z0), (x0 + 1, 6, z0), (x0 + 1, 6, z0 + 1), (x0, 6, z0 + 1)
+            s.add(Triangle((a, b, c)), glow, important=True)
+            s.add(Triangle((a, c, d)), glow, important=True)
+            n += 2
+    assert n == 32
+    s.set_options(False, 0)
+    desc = s.flatten(RendererParam(48, 48, max_depth=4), PerspectiveCameraParam((0, 3, -14), (0, 3, 0), 40.0))
+    assert desc.contents.n_lights == 32
+    spp = 192
+    packets, _ = oracle.render(desc, spp, seed=11, mode=2)
+    rule, _ = oracle.render(desc, spp, seed=12, mode=3)
+    m2, m3 = packets.mean() / spp, rule.mean() / spp
+    assert m2 > 0.01 and abs(m3 - m2) <= 0.03 * m2, (m2, m3)

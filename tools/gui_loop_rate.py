@@ -17,17 +17,18 @@ r = Renderer(scene.renderer_param, scene.camera_param, scene)
 r.render_pass()
 
 
-async def run(n_tasks):
+async def run(n_tasks, shared):
     result = RenderResult(w, h)
     stop = time.perf_counter() + seconds
 
     async def worker():
         while time.perf_counter() < stop:
-            result.add(await r.render())
+            result.add(await r.render(shared=shared))
     t0 = time.perf_counter()
     await asyncio.gather(*[worker() for _ in range(n_tasks)])
     return result._count / (time.perf_counter() - t0)
 
-for n in (1, 4, 16, 64):
-    rate = asyncio.run(run(n))
-    print(f"{name} {w}x{h}: {n:3d} render() in flight: {rate:7.1f} passes/s = {rate * w * h / 1e6:7.1f} Mpaths/s", flush=True)
+for shared in (False, True):
+    for n in (1, 4, 16, 64):
+        rate = asyncio.run(run(n, shared))
+        print(f"{name} {w}x{h}: {n:3d} render({'shared=True' if shared else ''}) in flight: {rate:7.1f} passes/s = {rate * w * h / 1e6:7.1f} Mpaths/s", flush=True)
