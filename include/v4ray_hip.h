@@ -254,8 +254,9 @@ int v4r_render(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_t pas
 int v4r_render_rows(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_t pass_stride, uint32_t n_passes, uint32_t row0,
                     uint32_t n_rows);
 
-/* v4r_render for callers that cannot allocate device memory: code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc.  It has no counterpart in the reference.  Same arguments, same passes, same
+/* v4r_render for callers that cannot allocate device memory: tight serving loops, harnesses that forbid hipMalloc,
+ * code that must not disturb a HIP graph capture going on elsewhere in the process (recording this call itself into a
+ * graph is not covered by a test: it records and waits for events of the handle).  It has no counterpart in the reference.  Same arguments, same passes, same
  * random streams and the same accumulator as v4r_render -- the image is bit-identical -- but the wavefront queues,
  * segment counters and stack-spill slab live in a V4R_NOALLOC_SCRATCH_BYTES array that is part of the library's
  * device image (every GPU the library runs on holds it until the process ends), and the call makes no hipMalloc,

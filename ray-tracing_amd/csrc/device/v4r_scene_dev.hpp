@@ -720,11 +720,28 @@ V4R_DEV uint32_t f32_to_u32_sat(float x) {  // Rust `as u32`
     return (uint32_t)x;
 }
 
-// Perlin::noise + perlin_interp, texture/noise.rs:41-89,109-140
-V4R_DEV float perlin_noise(const float4 *vec, const uint8_t *perm, V3 p) {
+// Perlin::noise + perlin_interp, texture/noise.rs:41-89,109-140, in two halves: the lattice cell of a point (its
+// fractional position and the six permutation bytes its corners hash from), and the interpolated gradient noise of a
+// cell.  Split so that Perlin::turb can ask for the next octave's permutation bytes before it waits for this
+// octave's gradients: the two table look-ups of an octave depend on each other, the octaves do not.
+struct PerlinCell {
+    float u, v, w;
+    uint32_t px0, px1, py0, py1, pz0, pz1;  // perm_x[i], perm_x[i + 1], perm_y[j], perm_y[j + 1], perm_z[k], perm_z[k + 1]
+};
+template <class PermPtr>
+V4R_DEV PerlinCell perlin_cell(PermPtr perm, V3 p) {
     float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
-    float u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    PerlinCell c;
+    c.u = p.x - fx, c.v = p.y - fy, c.w = p.z - fz;
     uint32_t i = (uint32_t)f32_to_i32_sat(fx), j = (uint32_t)f32_to_i32_sat(fy), k = (uint32_t)f32_to_i32_sat(fz);
+    c.px0 = perm[i & 255u], c.px1 = perm[(i + 1u) & 255u];
+    c.py0 = perm[256 + (j & 255u)], c.py1 = perm[256 + ((j + 1u) & 255u)];
+    c.pz0 = perm[512 + (k & 255u)], c.pz1 = perm[512 + ((k + 1u) & 255u)];
+    return c;
+}
+template <class VecPtr>
+V4R_DEV float perlin_noise(VecPtr vec, const PerlinCell &cell) {
+    const float u = cell.u, v = cell.v, w = cell.w;
     float uu = u * u * (3.0f - u * 2.0f);
     float vv = v * v * (3.0f - v * 2.0f);
     float ww = w * w * (3.0f - w * 2.0f);
@@ -738,8 +755,8 @@ V4R_DEV float perlin_noise(const float4 *vec, const uint8_t *perm, V3 p) {
     for (int di = 0; di < 2; ++di)
 #pragma unroll
         for (int dj = 0; dj < 2; ++dj) {
-            uint32_t base = perm[(i + di) & 255u] ^ perm[256 + ((j + dj) & 255u)];
-            float4 c0 = vec[base ^ perm[512 + (k & 255u)]], c1 = vec[base ^ perm[512 + ((k + 1u) & 255u)]];
+            uint32_t base = (di ? cell.px1 : cell.px0) ^ (dj ? cell.py1 : cell.py0);
+            const auto c0 = vec[base ^ cell.pz0], c1 = vec[base ^ cell.pz1];
             float du = u - (float)di, dv = v - (float)dj;
             pair d = (pair{c0.x, c1.x} * du + pair{c0.y, c1.y} * dv) + pair{c0.z, c1.z} * dw;
             float wij = (di ? uu : 1.0f - uu) * (dj ? vv : 1.0f - vv);
@@ -750,6 +767,20 @@ V4R_DEV float perlin_noise(const float4 *vec, const uint8_t *perm, V3 p) {
     return accum;
 }
 
+// Perlin::turb, texture/noise.rs:91-107; the next octave's permutation bytes are asked for before this octave's gradients are waited for
+template <class VecPtr, class PermPtr>
+V4R_DEV float perlin_turb(VecPtr vec, PermPtr perm, V3 q, uint32_t depth) {
+    float accum = 0.0f, weight = 1.0f;
+    PerlinCell cell = perlin_cell(perm, q);
+    for (uint32_t dpt = 0; dpt < depth; ++dpt) {
+        q = q * 2.0f;
+        const PerlinCell next = perlin_cell(perm, q);  // (one cell past the last octave: six bytes of a table that is always there)
+        accum += weight * perlin_noise(vec, cell);
+        weight *= 0.5f;
+        cell = next;
+    }
+    return accum;
+}
 // Texture::value for the four texture kinds; `uvf` computes (u,v) on demand.
 // NOISE = false compiles the Perlin branch out, for material classes whose texture trees hold no noise
 // texture (the eight unrolled lattice terms cost ~25 registers).
@@ -793,12 +824,7 @@ V4R_DEV V3 texture_value(const SceneDev &S, uint4 root0, uint4 root1, V3 p, UV u
             const float4 *vec = S.perlin_vec + 256 * (size_t)t[5];
             const uint8_t *perm = S.perlin_perm + 768 * (size_t)t[5];
             V3 q = p * scale;
-            float accum = 0.0f, weight = 1.0f;
-            for (uint32_t dpt = 0; dpt < depth; ++dpt) {
-                accum += weight * perlin_noise(vec, perm, q);
-                weight *= 0.5f;
-                q = q * 2.0f;
-            }
+            const float accum = perlin_turb(vec, perm, q, depth);
             float g = fabsf(accum);
             return v3(g, g, g);
         }
