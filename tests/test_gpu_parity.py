@@ -109,9 +109,13 @@ def test_render_matches_oracle_per_pixel(name, spp, flags):
     scale = np.abs(img_o).max(axis=2) + 1e-2 * spp
     diff = np.abs(img_d - img_o).max(axis=2) / scale
     close = float((diff < 2e-3).mean())
-    print(f"{name}: pixels within 2e-3: {close:.4f}; mean device {img_d.mean():.6f} oracle {img_o.mean():.6f}")
-    assert close >= 0.995, close
-    assert abs(img_d.mean() - img_o.mean()) <= 0.01 * abs(img_o.mean()) + 1e-6
+    # what the pixels that differ weigh: their share of the image's radiance
+    far = diff >= 2e-3
+    share = float(np.abs(img_d - img_o).sum(axis=2)[far].sum() / np.abs(img_o).sum())
+    print(f"{name}: pixels within 2e-3: {close:.5f}; the others hold {share:.2e} of the image sum; mean device {img_d.mean():.6f} oracle {img_o.mean():.6f}")
+    assert close >= 0.998, close   # (measured 0.9989 - 1.0)
+    assert share <= 2e-4, share   # (measured <= 3.3e-5)
+    assert abs(img_d.mean() - img_o.mean()) <= 0.002 * abs(img_o.mean()) + 1e-6
     r.close()
 
 
@@ -218,6 +222,42 @@ def test_random_scenes_match_oracle(seed, n_shapes, tree, monkeypatch):
     close = np.abs(img_d - img_o).max(axis=2) <= 2e-3 * (np.abs(img_o).max(axis=2) + 0.04)
     print(f"random scene {seed}: {same.mean():.5f} of the rays, {close.mean():.4f} of the pixels agree")
     assert close.mean() >= 0.99, float(close.mean())
+    r.close()
+
+
+@pytest.mark.parametrize("seed,tree", [(10, None), (11, "8"), (12, "4"), (13, "8"), (14, None)])
+def test_fuzzed_scenes_and_cameras_match_oracle(seed, tree, monkeypatch):
+    """Five seeds of tools/fuzz_parity.py: an 800-shape random scene under a random camera (position, field of view, lens,
+    odd image size, depth budget 1-30, antialiasing on or off), with the tree the renderer picks or one forced: closest
+    hits of 30 000 random rays and a 4-pass image against the oracle's reference-order traversal."""
+    if tree:
+        monkeypatch.setenv("V4R_WIDE", tree)
+    scene = random_scene(seed, 800)
+    rng = np.random.default_rng(1000 + seed)
+    eye = rng.normal(size=3)
+    eye = tuple(float(x) for x in eye / np.linalg.norm(eye) * rng.uniform(5, 40))
+    cam = PerspectiveCameraParam(eye, tuple(float(x) for x in rng.uniform(-3, 3, size=3)), float(rng.uniform(20, 90)),
+                                 aperture=float(rng.choice([0.0, 0.3, 2.0])), focus_dist=float(rng.uniform(5, 30)))
+    param = RendererParam(int(rng.integers(17, 97)), int(rng.integers(9, 71)), max_depth=int(rng.integers(1, 30)),
+                          antialias=bool(rng.integers(0, 2)))
+    r = Renderer(param, cam, scene)
+    n = 30000
+    o = rng.uniform(-14, 14, size=(n, 3)).astype(np.float32)
+    v = rng.normal(size=(n, 3)).astype(np.float32)
+    v = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+    prim_d, t_d = r.trace_rays(o, v, seed=seed)
+    prim_o, t_o = oracle.trace_rays(r.desc, o, v, seed=seed)
+    same = prim_d == prim_o
+    hit = same & (prim_o != MISS)
+    rel = np.abs(t_d[hit] - t_o[hit]) / np.abs(t_o[hit])
+    assert same.mean() >= 0.999 and np.quantile(rel, 0.999) <= 1e-5, (same.mean(), np.quantile(rel, 0.999))
+    r.render_passes(4)
+    img_d, _ = r.read_accumulator()
+    img_o, _ = oracle.render(r.desc, 4, seed=r.seed)
+    assert np.isnan(img_d).sum() == np.isnan(img_o).sum()
+    assert abs(np.nanmean(img_d) - np.nanmean(img_o)) <= 0.02 * abs(np.nanmean(img_o)) + 1e-6
+    print(f"fuzz seed {seed}, {r.read_tree()['width']}-wide tree, {param.width}x{param.height}, depth {param.max_depth}: ids {same.mean():.5f}, "
+          f"t to {np.quantile(rel, 0.999):.1e}")
     r.close()
 
 
