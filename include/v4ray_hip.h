@@ -265,8 +265,10 @@ int v4r_render_rows(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_
  * stack-spill slab and segment counters -- about 300 000 for a shallow tree, about 100 000 for the 79 488-triangle
  * bunny; larger images, and scenes whose tree is too deep, get V4R_E_LIMIT with the numbers in v4r_last_error().
  * Passes run in batches of scratch_slots / (width x height).  The scratch is shared by every renderer on the same
- * GPU and keeps the previous call's contents (the call clears the counters it needs at zero): calls that overlap
- * on one GPU -- two handles on different streams or threads -- race; serialise them. */
+ * GPU and keeps the previous call's contents (the call clears the counters it needs at zero).  Calls from several
+ * handles or threads on one GPU do not race: each call's stream waits for the event the previous call on that GPU
+ * recorded (the events are created with the first renderer on a GPU, not by this call), so they run one behind the
+ * other on the device. */
 #define V4R_NOALLOC_SCRATCH_BYTES (48u << 20)
 int v4r_render_noalloc(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint32_t pass_stride,
                        uint32_t n_passes);

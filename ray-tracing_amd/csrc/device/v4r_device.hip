@@ -967,6 +967,13 @@ struct Pipe {
     uint32_t grid_trace = 0, grid_tail = 0;  // workgroups of its traversal launches (the spill slab has one column per thread)
 };
 
+// One GPU's copy of `scratch` and what keeps its users apart (see scratch_of_device).
+struct DeviceScratch {
+    unsigned char *ptr = nullptr;
+    hipEvent_t last_use = nullptr;  // recorded at the end of the latest v4r_render_noalloc on this GPU
+    bool used = false;
+    std::mutex mu;                  // held while a call queues its work: the order of the locks is the order on the device
+};
 struct v4r_renderer {
     std::recursive_mutex mu;  // host-side state of the handle: every entry point holds it for its whole call
     int device = 0;
@@ -1011,6 +1018,7 @@ struct v4r_renderer {
     uint32_t n_wide_nodes = 0;             // nodes of the tree the kernels traverse (S.nodes4)
     std::vector<uint32_t> media_direct;    // constant media tested before the tree (device numbering)
     unsigned char *scratch_ptr = nullptr;  // this device's copy of `scratch`
+    DeviceScratch *device_scratch = nullptr;  // ... and the event that serialises its users
     Pipe noalloc;                          // queues carved out of it (Q.cap = 0: the scene does not fit), on the public stream
     std::string noalloc_why;               // what did not fit, when Q.cap = 0
 
@@ -1628,18 +1636,26 @@ int ensure_pipe(v4r_renderer *r, Pipe &pipe, size_t need, size_t n_passes) {
     return V4R_OK;
 }
 
-// The address of this device's copy of `scratch` (the device must be current).  The array's name is a host-side
-// handle, not a device address: only the pointer returned here may be handed to kernels or memsets.
-int scratch_of_device(int device, unsigned char **out) {
+// One GPU's copy of `scratch`: its address (the array's name is a host-side handle, not a device address: only the
+// pointer obtained here with hipGetSymbolAddress may be handed to kernels or memsets) and what keeps its users apart --
+// every renderer on the GPU shares the array, so v4r_render_noalloc calls are queued one behind the other on the device:
+// each call first makes its stream wait for the event the previous call recorded (whatever handle or thread made it).
+// Created once per device and process, by the first v4r_renderer_create on that device; never destroyed.
+int scratch_of_device(int device, DeviceScratch **out) {  // (the device must be current)
     static std::mutex mu;
-    static std::vector<unsigned char *> known;
+    static std::vector<DeviceScratch *> known;
     std::lock_guard<std::mutex> hold(mu);
     if ((size_t)device >= known.size()) known.resize((size_t)device + 1, nullptr);
     if (!known[device]) {
         void *p = nullptr;
         HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
         if (!p) return set_error(V4R_E_HIP, "hipGetSymbolAddress returned a NULL scratch address");
-        known[device] = (unsigned char *)p;
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        DeviceScratch *ds = new DeviceScratch();
+        ds->ptr = (unsigned char *)p;
+        ds->last_use = e;
+        known[device] = ds;
     }
     *out = known[device];
     return V4R_OK;
@@ -2014,7 +2030,8 @@ int build(v4r_renderer *r, const v4r_scene_desc *given, uint32_t bvh_depth) {
     // which also gives v4r_trace_rays its stack spill slab.
     if (int rc = ensure_pipe(r, r->pipes[0], r->npix, 1)) return rc;
     // v4r_render_noalloc: this device's scratch array, carved into one more pipeline that runs on the public stream
-    if (int rc = scratch_of_device(r->device, &r->scratch_ptr)) return rc;
+    if (int rc = scratch_of_device(r->device, &r->device_scratch)) return rc;
+    r->scratch_ptr = r->device_scratch->ptr;
     r->noalloc.stream = r->stream;
     HIP_TRY(hipEventCreateWithFlags(&r->noalloc.done, hipEventDisableTiming));
     carve_noalloc(r, n_cu);
@@ -2400,12 +2417,20 @@ int v4r_render_noalloc(v4r_renderer *r, uint64_t seed, uint32_t first_pass, uint
     if (r->S.packet_rule) batch = std::min(batch, NOALLOC_COUNTED_PASSES);
     if (batch >= 16u) batch &= ~15u;
     // One pipeline on the public stream: batches run one after the other, ordered after whatever the handle queued
-    // before (v4r_render ends by joining its pipelines into this stream) and before whatever it queues next.
-    for (uint32_t done = 0; done < n_passes;) {
+    // before (v4r_render ends by joining its pipelines into this stream) and before whatever it queues next -- and after
+    // the latest v4r_render_noalloc of any other handle on this GPU, which used the same scratch.
+    DeviceScratch &shared = *r->device_scratch;
+    std::lock_guard<std::mutex> turn(shared.mu);
+    if (shared.used) HIP_TRY(hipStreamWaitEvent(r->stream, shared.last_use, 0));
+    int rc = V4R_OK;
+    for (uint32_t done = 0; done < n_passes && rc == V4R_OK;) {
         uint32_t nb = std::min(batch, n_passes - done);
-        if (int rc = run_batch(r, pipe, seed, first_pass + done * pass_stride, pass_stride, nb, 0, r->S.height, false)) return rc;
+        rc = run_batch(r, pipe, seed, first_pass + done * pass_stride, pass_stride, nb, 0, r->S.height, false);
         done += nb;
     }
+    // (recorded on the error path too: whatever was queued must finish before the next user of the scratch starts)
+    if (hipEventRecord(shared.last_use, r->stream) == hipSuccess) shared.used = true;
+    if (rc != V4R_OK) return rc;
     r->n_passes += n_passes;
     return report_checks(r);
 }

@@ -70,3 +70,44 @@ def test_noalloc_rejects_an_image_beyond_the_scratch():
     r.render_passes(1)                  # the handle is still usable
     assert r.read_accumulator()[1] == 1
     r.close()
+
+
+def test_noalloc_calls_of_several_handles_and_threads_do_not_race():
+    """Every renderer on a GPU shares the one scratch array.  Calls from different handles -- queued back to back without
+    any synchronisation, and made from two threads at once -- run one behind the other on the device (each call's stream
+    waits for the event the previous call recorded), so each handle's image is exactly its own v4r_render image."""
+    import threading
+    refs, nas = [], []
+    for name, size in (("c3", (160, 160)), ("c2", (192, 108)), ("c3", (96, 128))):
+        ref, na = _pair(name, *size)
+        refs.append(ref)
+        nas.append(na)
+    passes = [24, 20, 32]
+    for ref, n in zip(refs, passes):
+        ref.render_passes(n)
+    # (1) one thread, three handles, three rounds of calls with nothing in between
+    for k in range(3):
+        for na, n in zip(nas, passes):
+            na.render_passes_noalloc(n // 4, first_pass=k * (n // 4))
+    # (2) the last quarter of every job from a thread of its own, all at once
+    errors = []
+
+    def last_quarter(na, n):
+        try:
+            na.render_passes_noalloc(n - 3 * (n // 4), first_pass=3 * (n // 4))
+        except Exception as e:  # reported below
+            errors.append(e)
+
+    threads = [threading.Thread(target=last_quarter, args=(na, n)) for na, n in zip(nas, passes)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for ref, na, n in zip(refs, nas, passes):
+        a, n_a = ref.read_accumulator()
+        b, n_b = na.read_accumulator()
+        assert n_a == n_b == n
+        assert np.array_equal(a, b), f"differs on {np.mean(a != b):.4f} of the values"
+    for r in refs + nas:
+        r.close()
