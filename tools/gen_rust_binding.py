@@ -33,23 +33,20 @@ def strip_comments(text):
 
 
 def structs(text):
+    """(struct name, [(field, C type, array dimensions)]) of every `typedef struct name { ... } name;`."""
     for m in re.finditer(r"typedef struct (\w+) \{(.*?)\} \1;", text, flags=re.S):
         fields = []
         for decl in m.group(2).split(";"):
             decl = " ".join(decl.split())
             if not decl:
                 continue
-            first, *rest = [d.strip() for d in decl.split(",")]
-            mm = re.match(r"(.*?)(\w+)((?:\[\d+\])*)$", first)
-            base = mm.group(1).strip()
-            pointer_base = base.rstrip("* ").strip()
-            for d in [first[len(mm.group(1)):]] + rest:
+            # `base declarator, declarator, ...`; a '*' belongs to the declarator it stands before
+            head = re.match(r"((?:const\s+)?\w+)\s*(.*)$", decl)
+            base = head.group(1)
+            for d in head.group(2).split(","):
                 dm = re.match(r"(\**)\s*(\w+)((?:\[\d+\])*)$", d.strip())
                 stars, name, dims = dm.group(1), dm.group(2), [int(x) for x in re.findall(r"\[(\d+)\]", dm.group(3))]
-                c_type = base if d is not rest or True else base
-                # a declarator list shares the base type; a '*' belongs to the declarator it stands before
-                this = (pointer_base + " " + "*" * (base.count("*") if name == mm.group(2) else len(stars))).strip()
-                fields.append((name, this, dims))
+                fields.append((name, (base + " " + stars).strip(), dims))
         yield m.group(1), fields
 
 
