@@ -611,3 +611,22 @@ def test_packet_statistics_rule_with_many_triangle_lights():
     rule, _ = oracle.render(desc, spp, seed=12, mode=3)
     m2, m3 = packets.mean() / spp, rule.mean() / spp
     assert m2 > 0.01 and abs(m3 - m2) <= 0.03 * m2, (m2, m3)
+
+
+@pytest.mark.parametrize("height", [6.0, 1.0, 0.3])
+def test_packet_statistics_rule_with_a_large_nearby_light(height):
+    """The rule estimates a packet mate's chance of hitting a light by cosine sampling from the light's centre, area and
+    normal (light_cosine_share) -- a point-light form.  A 6 x 6 light 6, 1 and 0.3 units above the floor it lights (from far
+    to nearly touching): the rule's image mean (mode 3) stays the mean of the reference's packets (mode 2)."""
+    s = Scene((0, 0, 0))
+    white = Lambertian(SolidColor((0.7, 0.7, 0.7)))
+    s.add(ZXRect(-8, 8, -8, 8, 0.0, True), white)
+    s.add(XYRect(-8, 8, 0, 8, 8.0, False), white)
+    s.add(ZXRect(-3, 3, -3, 3, height, False), DiffuseLight(SolidColor((4, 4, 4))), important=True)
+    s.set_options(False, 0)
+    desc = s.flatten(RendererParam(48, 48, max_depth=4), PerspectiveCameraParam((0, 3, -14), (0, 3, 0), 40.0))
+    spp = 256
+    packets, _ = oracle.render(desc, spp, seed=21, mode=2)
+    rule, _ = oracle.render(desc, spp, seed=22, mode=3)
+    m2, m3 = packets.mean() / spp, rule.mean() / spp
+    assert m2 > 0.01 and abs(m3 - m2) <= 0.03 * m2, (height, m2, m3)   # (measured: 0.1 %, 0.5 %, 2.1 %; two seeds of mode 2 differ by as much)
