@@ -435,6 +435,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if world > 1:
+        # the communicator's lazy set-up (connections, buffers for a message of this size) is not part of any step, whatever --warmup is
+        with torch.cuda.stream(stream):
+            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+        fence()
     for _ in range(args.warmup):
         clear()
         step()
