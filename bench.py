@@ -474,8 +474,9 @@ def main():
                                                           else f"bunny.obj, {args.c4_subdivide} subdivision(s) + earth-textured sphere in a Cornell box"),
                        "width": width, "height": height, "spp_per_gpu_per_step": spp, "max_depth": scene.renderer_param.max_depth,
                        "paths_per_step": npix * spp * world,
-                       "split": ("single GPU" if world == 1 else "sample-range (pass p on rank p mod N) + RCCL reduce" if args.split == "sample"
-                                 else "tile (rank r renders its band of rows) + RCCL reduce")},
+                       "split": ("single GPU" if world == 1 else
+                                 ("sample-range (pass p on rank p mod N)" if args.split == "sample" else "tile (rank r renders its band of rows)")
+                                 + (" + RCCL reduce" if dist.get_backend() == "nccl" else f" + {dist.get_backend()} reduce (rehearsal)"))},
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:
