@@ -97,6 +97,15 @@ V4R_DEV void store_ray(float4 *const col[3], uint32_t i, const PathState &p) {
     col[1][i] = make_float4(p.d.y, p.d.z, __uint_as_float(p.slot), p.thr.x);
     col[2][i] = make_float4(p.thr.y, p.thr.z, __uint_as_float(p.k0), __uint_as_float(p.k1));
 }
+// The same records written past the caches' keep-list: what a shading launch writes -- the next segment's rays, the radiance of
+// ended paths -- is not read again before the launches of the next segment (or the batch's resolve), by which time a cache line
+// written now is long gone; written the plain way it would displace the scene tables that every ray of every pipeline re-reads.
+V4R_DEV void stream_store(float4 *p, float4 v) { __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f *>(p)); }
+V4R_DEV void store_ray_streaming(float4 *const col[3], uint32_t i, const PathState &p) {
+    stream_store(&col[0][i], make_float4(p.o.x, p.o.y, p.o.z, p.d.x));
+    stream_store(&col[1][i], make_float4(p.d.y, p.d.z, __uint_as_float(p.slot), p.thr.x));
+    stream_store(&col[2][i], make_float4(p.thr.y, p.thr.z, __uint_as_float(p.k0), __uint_as_float(p.k1)));
+}
 V4R_DEV PathState unpack_ray(float4 a, float4 b, float4 c) {
     PathState p;
     p.o = v3(a.x, a.y, a.z);
@@ -712,8 +721,8 @@ __global__ __launch_bounds__(BLOCK, NOISE ? V4R_SHADE_MIN_WAVES_NOISE : 1) void 
         if (!valid) continue;  // a lane past the end of the queue shaded a copy of the last hit
         texel_fetches += fetched;
         if (!V4R_CHECK(Q.stats + 8, CHECK_PATH_SLOT, p.slot < Q.cap) || !V4R_CHECK(Q.stats + 8, CHECK_NEXT_RAY, out_base + i < Q.cap)) continue;
-        if (goes_on) store_ray(out, out_base + i, q);  // hit i of this class -> ray out_base + i of the next segment
-        else Q.rad[p.slot] = rad;
+        if (goes_on) store_ray_streaming(out, out_base + i, q);  // hit i of this class -> ray out_base + i of the next segment
+        else stream_store(&Q.rad[p.slot], rad);
     }
     if (COUNT) {
         unsigned long long s = wave_sum(n_shaded), x = wave_sum(texel_fetches);
@@ -1864,12 +1873,14 @@ int build(v4r_renderer *r, const v4r_scene_desc *given, uint32_t bvh_depth) {
     if (int rc = r->upload(&S.images, images.data(), images.size())) return rc;
     if (int rc = r->upload(&S.texels, texels.data(), texels.size())) return rc;
     std::vector<float4> pvec((size_t)d->n_perlin * 256);
-    std::vector<uint8_t> pperm((size_t)d->n_perlin * 768);
+    // perm_x, perm_y, perm_z of a table as 16-bit entries: entry i holds perm[i] in its low byte and perm[(i + 1) & 255] in
+    // its high byte, the two values a lattice cell needs along that axis, so that a cell costs three loads, not six
+    std::vector<uint16_t> pperm((size_t)d->n_perlin * 768);
     for (uint32_t i = 0; i < d->n_perlin; ++i) {
         for (int k = 0; k < 256; ++k) pvec[(size_t)i * 256 + k] = make_float4(d->perlin[i].vec[k][0], d->perlin[i].vec[k][1], d->perlin[i].vec[k][2], 0.0f);
-        std::memcpy(&pperm[(size_t)i * 768], d->perlin[i].perm_x, 256);
-        std::memcpy(&pperm[(size_t)i * 768 + 256], d->perlin[i].perm_y, 256);
-        std::memcpy(&pperm[(size_t)i * 768 + 512], d->perlin[i].perm_z, 256);
+        const uint8_t *axes[3] = {d->perlin[i].perm_x, d->perlin[i].perm_y, d->perlin[i].perm_z};
+        for (int a = 0; a < 3; ++a)
+            for (int k = 0; k < 256; ++k) pperm[(size_t)i * 768 + a * 256 + k] = (uint16_t)(axes[a][k] | (axes[a][(k + 1) & 255] << 8));
     }
     if (int rc = r->upload(&S.perlin_vec, pvec.data(), pvec.size())) return rc;
     if (int rc = r->upload(&S.perlin_perm, pperm.data(), pperm.size())) return rc;

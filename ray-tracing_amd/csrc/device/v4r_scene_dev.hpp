@@ -57,7 +57,7 @@ struct SceneDev {
     const uint4 *images;         // {first texel, width, height, 0}
     const uint32_t *texels;      // RGBA8, one word per texel
     const float4 *perlin_vec;    // 256 x float4 per table
-    const uint8_t *perlin_perm;  // 768 bytes per table: perm_x, perm_y, perm_z
+    const uint16_t *perlin_perm; // 768 entries per table: perm_x, perm_y, perm_z; entry i = perm[i] | perm[(i + 1) & 255] << 8
     const uint32_t *lights;      // primitive indices
     const uint32_t *scene_index; // per primitive: its index in the scene (the device numbers primitives in the order of its tree's leaves)
     uint32_t n_nodes, n_prims, n_lights, flags;
@@ -721,7 +721,7 @@ V4R_DEV uint32_t f32_to_u32_sat(float x) {  // Rust `as u32`
 }
 
 // Perlin::noise + perlin_interp, texture/noise.rs:41-89,109-140, in two halves: the lattice cell of a point (its
-// fractional position and the six permutation bytes its corners hash from), and the interpolated gradient noise of a
+// fractional position and the six permutation bytes its corners hash from, read as three pairs), and the interpolated gradient noise of a
 // cell.  Split so that Perlin::turb can ask for the next octave's permutation bytes before it waits for this
 // octave's gradients: the two table look-ups of an octave depend on each other, the octaves do not.
 struct PerlinCell {
@@ -734,9 +734,10 @@ V4R_DEV PerlinCell perlin_cell(PermPtr perm, V3 p) {
     PerlinCell c;
     c.u = p.x - fx, c.v = p.y - fy, c.w = p.z - fz;
     uint32_t i = (uint32_t)f32_to_i32_sat(fx), j = (uint32_t)f32_to_i32_sat(fy), k = (uint32_t)f32_to_i32_sat(fz);
-    c.px0 = perm[i & 255u], c.px1 = perm[(i + 1u) & 255u];
-    c.py0 = perm[256 + (j & 255u)], c.py1 = perm[256 + ((j + 1u) & 255u)];
-    c.pz0 = perm[512 + (k & 255u)], c.pz1 = perm[512 + ((k + 1u) & 255u)];
+    const uint32_t px = perm[i & 255u], py = perm[256 + (j & 255u)], pz = perm[512 + (k & 255u)];  // each: this entry, the next << 8
+    c.px0 = px & 255u, c.px1 = px >> 8;
+    c.py0 = py & 255u, c.py1 = py >> 8;
+    c.pz0 = pz & 255u, c.pz1 = pz >> 8;
     return c;
 }
 template <class VecPtr>
@@ -774,7 +775,7 @@ V4R_DEV float perlin_turb(VecPtr vec, PermPtr perm, V3 q, uint32_t depth) {
     PerlinCell cell = perlin_cell(perm, q);
     for (uint32_t dpt = 0; dpt < depth; ++dpt) {
         q = q * 2.0f;
-        const PerlinCell next = perlin_cell(perm, q);  // (one cell past the last octave: six bytes of a table that is always there)
+        const PerlinCell next = perlin_cell(perm, q);  // (one cell past the last octave: three entries of a table that is always there)
         accum += weight * perlin_noise(vec, cell);
         weight *= 0.5f;
         cell = next;
@@ -822,7 +823,7 @@ V4R_DEV V3 texture_value(const SceneDev &S, uint4 root0, uint4 root1, V3 p, UV u
             float scale = __uint_as_float(t[4]);
             uint32_t depth = t[6];
             const float4 *vec = S.perlin_vec + 256 * (size_t)t[5];
-            const uint8_t *perm = S.perlin_perm + 768 * (size_t)t[5];
+            const uint16_t *perm = S.perlin_perm + 768 * (size_t)t[5];
             V3 q = p * scale;
             const float accum = perlin_turb(vec, perm, q, depth);
             float g = fabsf(accum);
