@@ -617,125 +617,6 @@ class Renderer:
                 device_lib().v4r_renderer_destroy(h)
 
     def __del__(self):
-        h, self._h = getattr(self, "_h", None), None
-        if h:
-            try:
-                host_lib().v4rh_scene_free(h)
-            except Exception:
-                pass
-
-    @classmethod
-    def from_json(cls, path, perlin_seed: int = 1) -> "Scene":
-        """serde_json::from_reader + build_scene (src/main.rs:31-34); also reads the renderer and camera blocks."""
-        h = C.c_void_p()
-        check_host(host_lib().v4rh_scene_load_json_file(os.fspath(path).encode(), perlin_seed, C.byref(h)))
-        return cls._adopt(h)
-
-    @classmethod
-    def from_json_text(cls, text: str, base_dir: str = "", perlin_seed: int = 1) -> "Scene":
-        h = C.c_void_p()
-        check_host(host_lib().v4rh_scene_load_json_text(text.encode(), base_dir.encode(), perlin_seed, C.byref(h)))
-        return cls._adopt(h)
-
-    @classmethod
-    def _adopt(cls, h):
-        s = cls((0, 0, 0), _handle=h)
-        lib = host_lib()
-        rp, cp = _abi.RendererParamC(), _abi.CameraParam()
-        check_host(lib.v4rh_scene_get_renderer(h, C.byref(rp)))
-        check_host(lib.v4rh_scene_get_camera(h, C.byref(cp)))
-        s._renderer_param = RendererParam._from_c(rp)
-        s._camera_param = PerspectiveCameraParam._from_c(cp)
-        return s
-
-    @property
-    def renderer_param(self) -> Optional[RendererParam]:
-        return self._renderer_param
-
-    @property
-    def camera_param(self) -> Optional[PerspectiveCameraParam]:
-        return self._camera_param
-
-    def _texture_id(self, tex: _Texture) -> int:
-        if not isinstance(tex, _Texture):
-            raise TypeError("expected a v4ray texture")
-        key = id(tex)
-        if key not in self._tex_ids:
-            self._tex_ids[key] = (tex._realize(self), tex)
-        return self._tex_ids[key][0]
-
-    def _material_id(self, mat: _Material) -> int:
-        if not isinstance(mat, _Material):
-            raise TypeError("expected a v4ray material")
-        key = id(mat)
-        if key not in self._mat_ids:
-            self._mat_ids[key] = (mat._realize(self), mat)
-        return self._mat_ids[key][0]
-
-    def add(self, shape: _Shape, material: _Material, important: bool = False) -> None:
-        """Scene::add (src/scene.rs:38-41); important=True is Scene::add_important (:52-61)."""
-        if not isinstance(shape, _Shape):
-            raise TypeError("expected a v4ray shape")
-        lib = host_lib()
-        mat = self._material_id(material)
-        h = shape._handle()
-        try:
-            check_host(lib.v4rh_scene_add(self._h, h, mat, int(bool(important))))
-        finally:
-            lib.v4rh_shape_free(h)
-
-    def __len__(self):
-        return host_lib().v4rh_scene_len(self._h)
-
-    def set_options(self, pretransform_triangles: bool = False, flags: int = 0) -> None:
-        check_host(host_lib().v4rh_scene_set_options(self._h, int(pretransform_triangles), flags))
-
-    def bounding_box(self, index: int) -> AABB:
-        out = (C.c_float * 6)()
-        check_host(host_lib().v4rh_scene_bounding_box(self._h, index, out))
-        return AABB(tuple(out[0:3]), tuple(out[3:6]))
-
-    def flatten(self, param: RendererParam, camera: PerspectiveCameraParam):
-        """Build the BVH and return a pointer to the flat v4r_scene_desc (owned by this scene)."""
-        lib = host_lib()
-        rp, cp = param._to_c(), camera._to_c()
-        check_host(lib.v4rh_scene_set_renderer(self._h, C.byref(rp)))
-        check_host(lib.v4rh_scene_set_camera(self._h, C.byref(cp)))
-        desc = C.POINTER(_abi.SceneDesc)()
-        check_host(lib.v4rh_scene_flatten(self._h, C.byref(desc)))
-        return desc
-
-
-# ---- Renderer --------------------------------------------------------------------------------------
-class Renderer:
-    """PyRenderer, src/renderer.rs:430-477.
-
-    `await renderer.render()` yields one distinct 1-spp pass as an (H, W, 3) float32 array, as the reference
-    does; callers accumulate passes themselves (main.py:759-769).  `render(shared=True)` lets the calls in
-    flight share one device job (for callers that only sum).  `render_passes` keeps the sum on
-    the device instead, which is what the benchmark and the CLI use.
-    """
-
-    def __init__(self, param: RendererParam, camera: PerspectiveCameraParam, scene: Scene, device: int = 0,
-                 seed: int = 0x5EED):
-        self.param, self.camera, self.scene = param, camera, scene
-        self.width, self.height = param.width, param.height
-        self.seed = int(seed)
-        self._next_pass = 0
-        self._lock = threading.Lock()  # render() may run on several executor threads at once (main.py:1986-1990)
-        self._pending, self._pending_lock, self._draining = [], threading.Lock(), False  # render() calls waiting for a batch
-        self._desc = scene.flatten(param, camera)
-        lib = device_lib()
-        h = C.c_void_p()
-        check_dev(lib.v4r_renderer_create(self._desc, int(device), C.byref(h)))
-        self._h = h
-
-    def close(self):
-        h, self._h = getattr(self, "_h", None), None
-        if h:
-            device_lib().v4r_renderer_destroy(h)
-
-    def __del__(self):
         try:
             self.close()
         except Exception:

@@ -245,3 +245,46 @@ def test_awaited_render_calls_all_see_a_failure():
     got = asyncio.run(run())
     assert len(got) == 6 and all(isinstance(e, v4ray_hip.V4RayError) for e in got)
     assert r._draining is False
+
+
+def test_close_waits_for_the_render_in_flight():
+    """close() takes the lock a render holds, so the handle is never destroyed under the thread that is using it."""
+    import threading
+    import time
+    r = _bare_renderer(lambda n: None)
+    r._lock = threading.Lock()
+    order = []
+
+    def rendering():
+        with r._lock:
+            order.append("render starts")
+            time.sleep(0.05)
+            order.append("render ends")
+
+    t = threading.Thread(target=rendering)
+    t.start()
+    while not order:
+        time.sleep(0.001)
+    r.close()
+    order.append("closed")
+    t.join()
+    assert order == ["render starts", "render ends", "closed"]
+
+
+def test_the_package_defines_every_top_level_name_once():
+    import ast
+    import os
+    for name in ("__init__.py", "_abi.py", "scenes.py", "distributed.py"):
+        path = os.path.join(os.path.dirname(v4ray_hip.__file__), name)
+        seen = {}
+        for node in ast.parse(open(path).read()).body:
+            if isinstance(node, (ast.ClassDef, ast.FunctionDef)):
+                assert node.name not in seen, f"{name}: {node.name} is defined at lines {seen[node.name]} and {node.lineno}"
+                seen[node.name] = node.lineno
+            if isinstance(node, ast.ClassDef):
+                methods = {}
+                for m in node.body:
+                    if isinstance(m, ast.FunctionDef):
+                        decorated = any(isinstance(d, ast.Attribute) and d.attr in ("setter", "deleter") for d in m.decorator_list)
+                        assert decorated or m.name not in methods, f"{name}: {node.name}.{m.name} is defined twice"
+                        methods[m.name] = m.lineno
