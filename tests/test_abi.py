@@ -67,7 +67,7 @@ def test_renderer_fails_loudly_without_a_gpu():
         Renderer(s.renderer_param, s.camera_param, s)
 
 
-# ---- the three descriptions of the ABI agree: the C header, the ctypes mirror, the Rust text of INTEGRATION.md ----------
+# ---- the three descriptions of the ABI agree: the C header, the ctypes mirror, the Rust binding text of the integration notes ----------
 CTYPES_OF = {"v4r_bvh_node": _abi.BvhNode, "v4r_prim": _abi.Prim, "v4r_xform": _abi.Xform, "v4r_tri_shading": _abi.TriShading,
              "v4r_medium": _abi.Medium, "v4r_material": _abi.Material, "v4r_texture": _abi.Texture, "v4r_image": _abi.Image,
              "v4r_perlin": _abi.Perlin, "v4r_camera": _abi.Camera, "v4r_scene_desc": _abi.SceneDesc, "v4r_stats": _abi.Stats,
@@ -166,7 +166,7 @@ def camel(name):
 
 def test_ctypes_and_rust_struct_layouts_match_the_header(tmp_path):
     """Field order, offsets and sizes of every struct of include/v4ray_hip.h as gcc lays them out, against the ctypes
-    mirror the tests call through and against the #[repr(C)] structs of the Rust binding text in INTEGRATION.md."""
+    mirror the tests call through and against the #[repr(C)] structs of the Rust binding text in the integration notes."""
     layout = c_layout(tmp_path)
     rust = rust_structs(rust_text())
     rl = rust_layout(rust)

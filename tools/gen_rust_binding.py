@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Print the Rust side of include/v4ray_hip.h: one #[repr(C)] struct per C struct, the constants, and the extern "C"
-block -- the text of INTEGRATION.md section 1 (tests/test_abi.py checks that text against the header field by field).
+block -- the binding text a maintainer of the reference would add (tests/test_abi.py checks the copy in the integration notes
+against the header field by field).
 
     python tools/gen_rust_binding.py > /tmp/hip.rs
 """
