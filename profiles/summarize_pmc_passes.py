@@ -84,7 +84,8 @@ out = {"command": f"V4R_PIPES=1 rocprofv3 --pmc <one counter set per pass> --out
        "note": "FETCH_SIZE/WRITE_SIZE are KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request, so read bytes = 2 x "
                "FETCH_SIZE x 1024. SQ_*_CYCLES count quad-cycles summed over waves; GRBM_GUI_ACTIVE is summed over the 8 XCDs. "
                "hbm_frac = HBM bytes / exclusive kernel seconds / 8 TB/s. valu_issue_frac = SQ_INSTS_VALU x 2 cycles / "
-               "(1024 SIMDs x kernel cycles): the share of the vector issue slots the kernel used.",
+               "(1024 SIMDs x kernel cycles): the share of the vector issue slots the kernel used. resident_waves_per_simd = "
+               "SQ_WAVE_CYCLES x 4 / (1024 SIMDs x kernel cycles): the occupancy the launches reached on average (of 8 possible).",
        "kernels": {}}
 tot_bytes = tot_secs = 0.0
 for k in sorted(f):
@@ -111,6 +112,7 @@ for k in sorted(f):
                   "wave_time_issuing": round(s["SQ_ACTIVE_INST_ANY"] / wc, 3),
                   "wave_time_issue_stalled": round(s["SQ_WAIT_INST_ANY"] / wc, 3),
                   "wave_time_waiting_on_memory_or_barrier": round(a["SQ_WAIT_ANY"] / wc, 3),
+                  "resident_waves_per_simd": round(wc * 4 / (SIMDS * gui), 2),
                   "kernel_cycles": gui,
                   "clock_GHz": round(gui / t / 1e9, 3) if t else None,
                   "ta_busy": round(a["TA_TA_BUSY_sum"] / (256 * gui), 3),
