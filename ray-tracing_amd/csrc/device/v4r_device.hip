@@ -302,9 +302,9 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
     constexpr bool second = SECOND;
     constexpr bool WIDE8 = TREE != TREE_4_WIDE;
     __shared__ uint2 lds_stack[lds_depth(WIDE8) * BLOCK];
-    __shared__ uint32_t s_base;
-    __shared__ uint32_t s_cnt[2][CLS_COUNT + 1];  // per destination ([CLS_COUNT]: rays given up), one set per chunk parity
-    __shared__ uint32_t s_where[RAYS_PER_THREAD * BLOCK];  // per ray of the chunk: class << 16 | rank among the chunk's hits of that class
+    __shared__ uint32_t s_cnt[2][CLS_COUNT + 1];  // per destination ([CLS_COUNT]: rays given up), one set per pool in use
+    __shared__ uint32_t s_where[RAYS_PER_THREAD * BLOCK];  // as 2 x RAYS_PER_THREAD * BLOCK uint16: per ray of a pool, destination << 10 | rank
+    __shared__ uint32_t s_pool[2][2], s_next[2], s_done[2], s_free[2], s_current, s_finished;
     __shared__ v4f s_top[8 * (WIDE8 ? TOP_NODES_8 : TOP_NODES)];
     StackT<lds_depth(WIDE8)> st;
     stage_tree_top(S, s_top, st);  // the chunk loop below synchronises before the first traversal
@@ -335,210 +335,276 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
     unsigned long long clk_fetch = 0, clk_end = 0, clk_chunk = 0, clk_traverse = 0, wave_rays = 0;
     const unsigned long long clk_start = COUNT ? phase_clock() : 0ull;
 #endif
-    // The chunk's bookkeeping costs two barriers and one trip to the global counters: when the chunk's rays are done, the
-    // first threads add its counts to the segment's (one atomic per destination) while another takes the next chunk from
-    // the cursor; after the second barrier every thread writes its rays' queue entries and goes on with the next chunk.
-    // The counts of consecutive chunks live in two sets, so that the next chunk's set is cleared between the barriers
-    // of this one and a fast wave cannot rank into a set that is still being read.
-    if (threadIdx.x == 0) s_base = blockIdx.x * chunk;
-    if (threadIdx.x <= CLS_COUNT) s_cnt[0][threadIdx.x] = 0;
-    uint32_t parity = 0;
+    // A workgroup takes the queue in pools of `chunk` rays and hands a pool out to its waves in groups of 64 rays through an LDS
+    // word; no wave waits for another at a barrier.  The waves rank a pool's rays per destination with LDS atomics (s_cnt,
+    // s_where); the wave that finishes the pool's last group adds the pool's counts to the segment's (one atomic per
+    // destination) and writes the queue entries of all its rays, while the others are already at work on the next pool, which
+    // the first wave to find the pool used up took from the cursor.  Two pools are in use at a time (the one being handed out
+    // and the one whose last groups are still being traced) in two sets of LDS; a set is reused two pools later, after its
+    // pool's entries are written.  s_next[set] packs the pool's sequence number, its number of groups and the next group to hand
+    // out into one word, so that one LDS atomic tells a wave all three consistently, whichever pool lives in the set by then.
+    constexpr uint32_t WHERE_NONE = 0xFFFFu;  // s_where: destination << 10 | rank among the pool's rays with that destination
+    constexpr uint32_t SPIN_LIMIT = 1u << 22;  // (a wave that waited this long for another gives the launch up: the checked build reports it)
+    auto pack_next = [](uint32_t seq, uint32_t n_groups) { return (seq << 17) | (n_groups << 12); };
+    auto pool_count = [&](uint32_t base) { return base < n_in ? min(chunk, n_in - base) : 0u; };
+    if (threadIdx.x == 0) {
+        const uint32_t count0 = pool_count(blockIdx.x * chunk);
+        s_pool[0][0] = blockIdx.x * chunk;
+        s_pool[0][1] = count0;
+        s_next[0] = pack_next(0u, (count0 + 63u) / 64u);
+        s_next[1] = pack_next(0x7FFFu, 0u);
+        s_done[0] = s_done[1] = 0u;
+        s_free[0] = 0u;
+        s_free[1] = 1u;
+        s_current = 0u;
+        s_finished = count0 == 0u ? 1u : 0u;
+    }
+    if (threadIdx.x < 2 * (CLS_COUNT + 1)) (&s_cnt[0][0])[threadIdx.x] = 0;
     __syncthreads();
+    // one LDS atomic for the wave, its result in every lane (and in a scalar register)
+    auto wave_fetch_add = [](uint32_t *word, uint32_t v) {
+        uint32_t r = 0u;
+        if (lane_id() == 0) r = __hip_atomic_fetch_add(word, v, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+    };
+    auto peek = [](const uint32_t *word) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)); };
     while (true) {
 #ifdef V4R_PHASE_CLOCKS
         unsigned long long tc = COUNT ? phase_clock() : 0ull;
 #endif
-        const uint32_t base = s_base;
-        if (base >= n_in) break;
+        if (peek(&s_finished) != 0u) break;
+        const uint32_t p = peek(&s_current) & 1u;
+        const uint32_t word = wave_fetch_add(&s_next[p], 1u);
+        const uint32_t seq = word >> 17, n_groups = (word >> 12) & 31u, g = word & 0xFFFu;
+        if (g >= n_groups) {  // the pool in this set is used up
+            bool stuck = false;
+            if (g == n_groups) {  // ... and this wave is the first to find it so: it opens pool seq + 1 in the other set
+                for (uint32_t spins = 0; peek(&s_free[p ^ 1u]) == 0u; ++spins) {  // (pool seq - 1 still has a group out)
+                    if (spins >= SPIN_LIMIT) {
+                        stuck = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (!stuck && lane_id() == 0) {
+                    const uint32_t nb = gridDim.x * chunk + atomicAdd(second ? &ctr->second_cursor : &ctr->trace_cursor, chunk);
+                    const uint32_t nc = pool_count(nb);
+                    if (nc == 0u) {
+                        __hip_atomic_store(&s_finished, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    } else {
+                        s_pool[p ^ 1u][0] = nb;
+                        s_pool[p ^ 1u][1] = nc;
+                        s_free[p ^ 1u] = 0u;
+                        __hip_atomic_store(&s_next[p ^ 1u], pack_next((seq + 1u) & 0x7FFFu, (nc + 63u) / 64u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_store(&s_current, seq + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            } else {  // another wave is opening the next pool
+                for (uint32_t spins = 0; peek(&s_current) == seq && peek(&s_finished) == 0u; ++spins) {
+                    if (spins >= SPIN_LIMIT) {
+                        stuck = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            if (!V4R_CHECK(Q.stats + 8, CHECK_POOL_WAIT, !stuck) || stuck) break;
+#ifdef V4R_PHASE_CLOCKS
+            if (COUNT) clk_chunk += phase_clock() - tc;
+#endif
+            continue;
+        }
+        const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_pool[p][0]), count = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_pool[p][1]);
 #ifdef V4R_PHASE_CLOCKS
         if (COUNT) clk_chunk += phase_clock() - tc;
 #endif
-
         {
-#pragma unroll 1
-            for (uint32_t j = 0; j < per_thread; ++j) {
 #ifdef V4R_PHASE_CLOCKS
-                const unsigned long long ta = COUNT ? phase_clock() : 0ull;
-                wave_rays++;
+            const unsigned long long ta = COUNT ? phase_clock() : 0ull;
+            wave_rays++;
 #endif
-                uint32_t pos = base + j * BLOCK + threadIdx.x;
-                bool active = pos < n_in;
-                uint32_t i = active ? pos : n_in - 1u;  // index of the ray in the queue of this segment
-                if (second) i = Q.given_up[i];
-                const uint32_t ii = i;
-                V3 o, d;
-                uint32_t pass_in_batch = 0, pixel = 0;  // PRIMARY only
-                uint32_t slot = 0;                       // later segments, while rays are counted per shape
-                if (PRIMARY) {
-                    // Renderer::sample + Camera::get_ray for queue entry ii (see ray_order); the ray record is
-                    // written further down, and only if the ray hits something: a miss ends the path here
-                    ray_order(A.order, S.width, npix, ii, pass_in_batch, pixel);  // pixel: within the band
-                    uint32_t k0, k1;
-                    path_key(A.seed_lo, A.seed_hi, A.first_pass + pass_in_batch * A.pass_stride, pixel + A.pixel_offset, k0, k1);
-                    camera_ray(S, pixel + A.pixel_offset, segment_key(k0, k1, 0u), false, o, d, A.order.inv_width);
-                } else {
-                    float4 a = rq[0][ii];
-                    o = v3(a.x, a.y, a.z);
-                    float2 b = *reinterpret_cast<const float2 *>(&rq[1][ii]);
-                    d = v3(a.w, b.x, b.y);
-                }
-                Best best;
-                best.t = V4R_INF;
-                best.prim = NO_PRIM;
-                best.u = best.v = 0.0f;
-                if (second) {  // the closest hit found before the ray was given up
-                    float4 h = Q.hitd[ii];
-                    best.t = h.x;
-                    best.prim = __float_as_uint(h.y);
-                    best.u = h.z;
-                    best.v = h.w;
-                }
-                // the random stream of the segment, needed only if the ray meets a constant medium
-                auto key = [&]() {
-                    uint32_t k0, k1;
-                    if (PRIMARY) {
-                        path_key(A.seed_lo, A.seed_hi, A.first_pass + pass_in_batch * A.pass_stride, pixel + A.pixel_offset, k0, k1);
-                    } else {
-                        float4 c = rq[2][ii];
-                        k0 = __float_as_uint(c.z);
-                        k1 = __float_as_uint(c.w);
-                    }
-                    return segment_key(k0, k1, seg);
-                };
-#ifdef V4R_PHASE_CLOCKS
-                const unsigned long long tb = COUNT ? phase_clock() : 0ull;
-                if (COUNT) clk_fetch += tb - ta;
-#endif
-                bool gave_up = traverse<COUNT, MEDIA, WIDE8>(S, o, d, active, st, best, cnt, key, second ? 0u : give_up_lanes, second);
-#ifdef V4R_PHASE_CLOCKS
-                const unsigned long long td = COUNT ? phase_clock() : 0ull;
-                if (COUNT) clk_traverse += td - tb;
-#endif
-                // (the ray's index as a value the compiler has not seen: the queue addresses below are then computed here, not
-                // before the traversal and carried through it in registers the traversal needs)
-                asm volatile("" : "+v"(i));
-                // what becomes of the ray: the queue it goes to (a shading class, or CLS_COUNT = given up), or none (its path ended)
-                uint32_t dest = DEST_NONE;
-                // Everything the end of a ray may need goes out in one burst of loads, before any of it is looked at: the
-                // class word of the primitive hit and the rest of the ray's record (path slot, throughput).  A wave holds
-                // rays that end in every possible way, so it would otherwise wait for one trip to memory per way, one after the other.
-                uint32_t info = 0u;
-                float4 bb = make_float4(0, 0, 0, 0), cc = bb;
-                if (active && !gave_up) {
-                    if (best.prim != NO_PRIM) info = S.prim_info[best.prim];
-                    if (!PRIMARY) bb = rq[1][i], cc = rq[2][i];
-                }
-                if (active && gave_up) {
-                    Q.hitd[i] = make_float4(best.t, __uint_as_float(best.prim), best.u, best.v);
-                    dest = (uint32_t)CLS_COUNT;
-                } else if (active) {
-                    if (COUNT) n_traced++;
-                    if (best.prim != NO_PRIM) {
-                        // Packet-statistics rule of the light pdf: count the pass's rays per Lambertian shape they end on.  A
-                        // counter that reaches V4R_PACKET_MANY_RAYS raises its "full" flag and is left alone from then on,
-                        // at this level and the deeper ones of the batch (walls would otherwise serialise the chip on a
-                        // handful of addresses -- every launch anew, until each compute unit has seen the flag; from that
-                        // count on the rule treats every packet as full).  The flag is read and written with plain
-                        // accesses: a stale 0 only costs one more increment.  Shapes full in every pass (build()) skip all of it.
-                        const uint32_t cls = info >> 24;
-                        uint32_t *n_rays = Q.shape_rays;
-                        uint32_t full = 1u;
-                        if (count_shape_rays && !(info & PRIM_INFO_ALWAYS_FULL)) {  // (a shape full in every pass is not counted at all)
-                            if (!PRIMARY) slot = __float_as_uint(bb.z);
-                            uint32_t pass = PRIMARY ? pass_in_batch : pass_of_slot(slot, npix, A.inv_npix);
-                            if (V4R_CHECK(Q.stats + 8, CHECK_RAY_COUNTER, (size_t)(pass + 1u) * S.n_prims <= Q.flags_offset)) {
-                                n_rays += (size_t)pass * S.n_prims + best.prim;
-                                // (a small shape's flag is never raised -- see below -- so it is not read: one trip to memory less
-                                // at the end of every ray that ends on a mesh triangle)
-                                full = (info & PRIM_INFO_SMALL) ? 0u : n_rays[Q.flags_offset];
-                            }
-                        }
-                        if (info & PRIM_INFO_PLAIN_LIGHT) {
-                            // DiffuseLight (material/diffuse_light.rs:19-22) of one colour on an untransformed rectangle: the
-                            // path ends here with throughput x emitted; nothing is queued for a shading launch.  The face test
-                            // is HitRecord::face_normal (hittable/mod.rs:146-154) against the rectangle's axis normal.
-                            const uint4 colour = S.prim_shade[2 * (size_t)best.prim];
-                            const float along = comp(d, (int)((info >> PRIM_INFO_AXIS_SHIFT) & 3u));
-                            const bool front = ((info & PRIM_INFO_POSITIVE) ? along : -along) < 0.0f;
-                            V3 e = front ? v3(__uint_as_float(colour.y), __uint_as_float(colour.z), __uint_as_float(colour.w)) : v3(0, 0, 0);
-                            if (PRIMARY) {
-                                Q.rad[pass_in_batch * npix + pixel] = make_float4(1.0f * e.x, 1.0f * e.y, 1.0f * e.z, 0.0f);
-                            } else {
-                                Q.rad[__float_as_uint(bb.z)] = make_float4(bb.w * e.x, cc.x * e.y, cc.y * e.z, 0.0f);
-                            }
-                            if (COUNT) n_lights++;
-                        } else {
-                            Q.hitd[i] = make_float4(best.t, __uint_as_float(best.prim), best.u, best.v);
-                            dest = cls;
-                            if (count_shape_rays && (cls == (uint32_t)CLS_LAMBERT || cls == (uint32_t)CLS_LAMBERT_NOISE) && full == 0u) {
-                                // A shape too small to expect many rays (a mesh triangle) is counted without waiting for
-                                // the counter's value: it will not fill, and a few percent of the rays end on such shapes,
-                                // so waiting would hold nearly every wave of the later segments for a trip to memory.
-                                // (The size class is a guess from the shape's share of the scene's area; a wrong guess
-                                // costs time -- contended or waited-for increments -- never a wrong count.)
-                                if (info & PRIM_INFO_SMALL) atomicAdd(n_rays, 1u);
-                                else if (atomicAdd(n_rays, 1u) + 1u >= V4R_PACKET_MANY_RAYS) n_rays[Q.flags_offset] = 1u;
-                            }
-                            if (PRIMARY) {
-                                PathState p;
-                                p.o = o;
-                                p.d = d;
-                                p.thr = v3(1, 1, 1);
-                                p.slot = pass_in_batch * npix + pixel;
-                                path_key(A.seed_lo, A.seed_hi, A.first_pass + pass_in_batch * A.pass_stride, pixel + A.pixel_offset, p.k0, p.k1);
-                                store_ray(rq, i, p);
-                            }
-                        }
-                    } else if (PRIMARY) {  // renderer.rs:184: a miss takes the background colour
-                        Q.rad[pass_in_batch * npix + pixel] = make_float4(S.bg[0], S.bg[1], S.bg[2], 0.0f);
-                    } else {
-                        Q.rad[__float_as_uint(bb.z)] = make_float4(bb.w * S.bg[0], cc.x * S.bg[1], cc.y * S.bg[2], 0.0f);
-                    }
-                }
-                // Rank of the ray among the chunk's rays with the same destination: the lanes of the wave that share a
-                // destination are found by ballot, one of them reserves their ranks with a single LDS atomic, and each
-                // takes the rank of its position among them.
-                uint32_t w = 0xFFFFFFFFu;
-                for (unsigned long long todo = __ballot(dest != DEST_NONE); todo != 0ull;) {
-                    const int leader = __ffsll((long long)todo) - 1;
-                    const uint32_t which = (uint32_t)__shfl((int)dest, leader, 64);
-                    const unsigned long long same = __ballot(dest == which);
-                    uint32_t first = 0u;
-                    if ((int)lane_id() == leader) first = atomicAdd(&s_cnt[parity][which], (uint32_t)__popcll(same));
-                    first = (uint32_t)__shfl((int)first, leader, 64);
-                    if (dest == which) w = (which << 16) | (first + (uint32_t)__popcll(same & ((1ull << lane_id()) - 1ull)));
-                    todo &= ~same;
-                }
-                s_where[j * BLOCK + threadIdx.x] = w;
-#ifdef V4R_PHASE_CLOCKS
-                if (COUNT) clk_end += phase_clock() - td;
-#endif
+        const uint32_t in_pool = g * 64u + lane_id();
+        uint32_t pos = base + in_pool;
+        bool active = in_pool < count;  // (base + count <= n_in)
+        uint32_t i = active ? pos : n_in - 1u;  // index of the ray in the queue of this segment
+        if (second) i = Q.given_up[i];
+        const uint32_t ii = i;
+        V3 o, d;
+        uint32_t pass_in_batch = 0, pixel = 0;  // PRIMARY only
+        uint32_t slot = 0;                       // later segments, while rays are counted per shape
+        if (PRIMARY) {
+            // Renderer::sample + Camera::get_ray for queue entry ii (see ray_order); the ray record is
+            // written further down, and only if the ray hits something: a miss ends the path here
+            ray_order(A.order, S.width, npix, ii, pass_in_batch, pixel);  // pixel: within the band
+            uint32_t k0, k1;
+            path_key(A.seed_lo, A.seed_hi, A.first_pass + pass_in_batch * A.pass_stride, pixel + A.pixel_offset, k0, k1);
+            camera_ray(S, pixel + A.pixel_offset, segment_key(k0, k1, 0u), false, o, d, A.order.inv_width);
+        } else {
+            float4 a = rq[0][ii];
+            o = v3(a.x, a.y, a.z);
+            float2 b = *reinterpret_cast<const float2 *>(&rq[1][ii]);
+            d = v3(a.w, b.x, b.y);
+        }
+        Best best;
+        best.t = V4R_INF;
+        best.prim = NO_PRIM;
+        best.u = best.v = 0.0f;
+        if (second) {  // the closest hit found before the ray was given up
+            float4 h = Q.hitd[ii];
+            best.t = h.x;
+            best.prim = __float_as_uint(h.y);
+            best.u = h.z;
+            best.v = h.w;
+        }
+        // the random stream of the segment, needed only if the ray meets a constant medium
+        auto key = [&]() {
+            uint32_t k0, k1;
+            if (PRIMARY) {
+                path_key(A.seed_lo, A.seed_hi, A.first_pass + pass_in_batch * A.pass_stride, pixel + A.pixel_offset, k0, k1);
+            } else {
+                float4 c = rq[2][ii];
+                k0 = __float_as_uint(c.z);
+                k1 = __float_as_uint(c.w);
             }
+            return segment_key(k0, k1, seg);
+        };
+#ifdef V4R_PHASE_CLOCKS
+        const unsigned long long tb = COUNT ? phase_clock() : 0ull;
+        if (COUNT) clk_fetch += tb - ta;
+#endif
+        bool gave_up = traverse<COUNT, MEDIA, WIDE8>(S, o, d, active, st, best, cnt, key, second ? 0u : give_up_lanes, second);
+#ifdef V4R_PHASE_CLOCKS
+        const unsigned long long td = COUNT ? phase_clock() : 0ull;
+        if (COUNT) clk_traverse += td - tb;
+#endif
+        // (the ray's index as a value the compiler has not seen: the queue addresses below are then computed here, not
+        // before the traversal and carried through it in registers the traversal needs)
+        asm volatile("" : "+v"(i));
+        // what becomes of the ray: the queue it goes to (a shading class, or CLS_COUNT = given up), or none (its path ended)
+        uint32_t dest = DEST_NONE;
+        // Everything the end of a ray may need goes out in one burst of loads, before any of it is looked at: the
+        // class word of the primitive hit and the rest of the ray's record (path slot, throughput).  A wave holds
+        // rays that end in every possible way, so it would otherwise wait for one trip to memory per way, one after the other.
+        uint32_t info = 0u;
+        float4 bb = make_float4(0, 0, 0, 0), cc = bb;
+        if (active && !gave_up) {
+            if (best.prim != NO_PRIM) info = S.prim_info[best.prim];
+            if (!PRIMARY) bb = rq[1][i], cc = rq[2][i];
+        }
+        if (active && gave_up) {
+            Q.hitd[i] = make_float4(best.t, __uint_as_float(best.prim), best.u, best.v);
+            dest = (uint32_t)CLS_COUNT;
+        } else if (active) {
+            if (COUNT) n_traced++;
+            if (best.prim != NO_PRIM) {
+                // Packet-statistics rule of the light pdf: count the pass's rays per Lambertian shape they end on.  A
+                // counter that reaches V4R_PACKET_MANY_RAYS raises its "full" flag and is left alone from then on,
+                // at this level and the deeper ones of the batch (walls would otherwise serialise the chip on a
+                // handful of addresses -- every launch anew, until each compute unit has seen the flag; from that
+                // count on the rule treats every packet as full).  The flag is read and written with plain
+                // accesses: a stale 0 only costs one more increment.  Shapes full in every pass (build()) skip all of it.
+                const uint32_t cls = info >> 24;
+                uint32_t *n_rays = Q.shape_rays;
+                uint32_t full = 1u;
+                if (count_shape_rays && !(info & PRIM_INFO_ALWAYS_FULL)) {  // (a shape full in every pass is not counted at all)
+                    if (!PRIMARY) slot = __float_as_uint(bb.z);
+                    uint32_t pass = PRIMARY ? pass_in_batch : pass_of_slot(slot, npix, A.inv_npix);
+                    if (V4R_CHECK(Q.stats + 8, CHECK_RAY_COUNTER, (size_t)(pass + 1u) * S.n_prims <= Q.flags_offset)) {
+                        n_rays += (size_t)pass * S.n_prims + best.prim;
+                        // (a small shape's flag is never raised -- see below -- so it is not read: one trip to memory less
+                        // at the end of every ray that ends on a mesh triangle)
+                        full = (info & PRIM_INFO_SMALL) ? 0u : n_rays[Q.flags_offset];
+                    }
+                }
+                if (info & PRIM_INFO_PLAIN_LIGHT) {
+                    // DiffuseLight (material/diffuse_light.rs:19-22) of one colour on an untransformed rectangle: the
+                    // path ends here with throughput x emitted; nothing is queued for a shading launch.  The face test
+                    // is HitRecord::face_normal (hittable/mod.rs:146-154) against the rectangle's axis normal.
+                    const uint4 colour = S.prim_shade[2 * (size_t)best.prim];
+                    const float along = comp(d, (int)((info >> PRIM_INFO_AXIS_SHIFT) & 3u));
+                    const bool front = ((info & PRIM_INFO_POSITIVE) ? along : -along) < 0.0f;
+                    V3 e = front ? v3(__uint_as_float(colour.y), __uint_as_float(colour.z), __uint_as_float(colour.w)) : v3(0, 0, 0);
+                    if (PRIMARY) {
+                        Q.rad[pass_in_batch * npix + pixel] = make_float4(1.0f * e.x, 1.0f * e.y, 1.0f * e.z, 0.0f);
+                    } else {
+                        Q.rad[__float_as_uint(bb.z)] = make_float4(bb.w * e.x, cc.x * e.y, cc.y * e.z, 0.0f);
+                    }
+                    if (COUNT) n_lights++;
+                } else {
+                    Q.hitd[i] = make_float4(best.t, __uint_as_float(best.prim), best.u, best.v);
+                    dest = cls;
+                    if (count_shape_rays && (cls == (uint32_t)CLS_LAMBERT || cls == (uint32_t)CLS_LAMBERT_NOISE) && full == 0u) {
+                        // A shape too small to expect many rays (a mesh triangle) is counted without waiting for
+                        // the counter's value: it will not fill, and a few percent of the rays end on such shapes,
+                        // so waiting would hold nearly every wave of the later segments for a trip to memory.
+                        // (The size class is a guess from the shape's share of the scene's area; a wrong guess
+                        // costs time -- contended or waited-for increments -- never a wrong count.)
+                        if (info & PRIM_INFO_SMALL) atomicAdd(n_rays, 1u);
+                        else if (atomicAdd(n_rays, 1u) + 1u >= V4R_PACKET_MANY_RAYS) n_rays[Q.flags_offset] = 1u;
+                    }
+                    if (PRIMARY) {
+                        PathState p;
+                        p.o = o;
+                        p.d = d;
+                        p.thr = v3(1, 1, 1);
+                        p.slot = pass_in_batch * npix + pixel;
+                        path_key(A.seed_lo, A.seed_hi, A.first_pass + pass_in_batch * A.pass_stride, pixel + A.pixel_offset, p.k0, p.k1);
+                        store_ray(rq, i, p);
+                    }
+                }
+            } else if (PRIMARY) {  // renderer.rs:184: a miss takes the background colour
+                Q.rad[pass_in_batch * npix + pixel] = make_float4(S.bg[0], S.bg[1], S.bg[2], 0.0f);
+            } else {
+                Q.rad[__float_as_uint(bb.z)] = make_float4(bb.w * S.bg[0], cc.x * S.bg[1], cc.y * S.bg[2], 0.0f);
+            }
+        }
+        // Rank of the ray among the chunk's rays with the same destination: the lanes of the wave that share a
+        // destination are found by ballot, one of them reserves their ranks with a single LDS atomic, and each
+        // takes the rank of its position among them.
+        uint32_t w = WHERE_NONE;
+        for (unsigned long long todo = __ballot(dest != DEST_NONE); todo != 0ull;) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const uint32_t which = (uint32_t)__shfl((int)dest, leader, 64);
+            const unsigned long long same = __ballot(dest == which);
+            uint32_t first = 0u;
+            if ((int)lane_id() == leader) first = atomicAdd(&s_cnt[p][which], (uint32_t)__popcll(same));
+            first = (uint32_t)__shfl((int)first, leader, 64);
+            if (dest == which) w = (which << 10) | (first + (uint32_t)__popcll(same & ((1ull << lane_id()) - 1ull)));
+            todo &= ~same;
+        }
+            reinterpret_cast<uint16_t *>(s_where)[p * (RAYS_PER_THREAD * BLOCK) + in_pool] = (uint16_t)w;
+#ifdef V4R_PHASE_CLOCKS
+            if (COUNT) clk_end += phase_clock() - td;
+#endif
         }
 #ifdef V4R_PHASE_CLOCKS
         tc = COUNT ? phase_clock() : 0ull;
 #endif
-        __syncthreads();
-        if (threadIdx.x <= CLS_COUNT) {
-            uint32_t n = s_cnt[parity][threadIdx.x];
-            uint32_t *total = threadIdx.x < CLS_COUNT ? &ctr->hit_count[threadIdx.x] : &ctr->given_up;
-            s_cnt[parity][threadIdx.x] = n ? atomicAdd(total, n) : 0u;
-            s_cnt[parity ^ 1u][threadIdx.x] = 0u;
-        } else if (threadIdx.x == CLS_COUNT + 1) {
-            s_base = gridDim.x * chunk + atomicAdd(second ? &ctr->second_cursor : &ctr->trace_cursor, chunk);
-        }
-        __syncthreads();
-#pragma unroll 1
-        for (uint32_t j = 0; j < per_thread; ++j) {
-            uint32_t pos = base + j * BLOCK + threadIdx.x;
-            uint32_t w = pos < n_in ? s_where[j * BLOCK + threadIdx.x] : 0xFFFFFFFFu;  // slots past the queue end were never traced
-            if (w != 0xFFFFFFFFu) {
-                uint32_t i = second ? Q.given_up[pos] : pos;
-                uint32_t k = w >> 16, idx = s_cnt[parity][k] + (w & 0xFFFFu);
-                if (V4R_CHECK(Q.stats + 8, CHECK_QUEUE_INDEX, idx < Q.cap && i < Q.cap)) (k < (uint32_t)CLS_COUNT ? Q.hit[k] : Q.given_up)[idx] = i;
+        // (the atomic orders this wave's ranks and s_where entries before the count that another wave may act on)
+        if (wave_fetch_add(&s_done[p], 1u) + 1u == n_groups) {
+            // the pool's last group: its counts go to the segment's, its rays to their queues
+            uint32_t first_of = 0u;
+            if (lane_id() <= (uint32_t)CLS_COUNT) {
+                const uint32_t n = s_cnt[p][lane_id()];
+                uint32_t *total = lane_id() < (uint32_t)CLS_COUNT ? &ctr->hit_count[lane_id()] : &ctr->given_up;
+                first_of = n ? atomicAdd(total, n) : 0u;
+                s_cnt[p][lane_id()] = 0u;
+            }
+            for (uint32_t it = 0; it < n_groups; ++it) {
+                const uint32_t e = it * 64u + lane_id();
+                const uint32_t w = e < count ? (uint32_t)reinterpret_cast<const uint16_t *>(s_where)[p * (RAYS_PER_THREAD * BLOCK) + e] : WHERE_NONE;
+                const uint32_t k = (w >> 10) & 7u;
+                const uint32_t idx = (uint32_t)__shfl((int)first_of, (int)k, 64) + (w & 0x3FFu);
+                if (w != WHERE_NONE) {
+                    const uint32_t i = second ? Q.given_up[base + e] : base + e;
+                    if (V4R_CHECK(Q.stats + 8, CHECK_QUEUE_INDEX, idx < Q.cap && i < Q.cap)) (k < (uint32_t)CLS_COUNT ? Q.hit[k] : Q.given_up)[idx] = i;
+                }
+            }
+            if (lane_id() == 0) {
+                s_done[p] = 0u;
+                __hip_atomic_store(&s_free[p], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
-        parity ^= 1u;
 #ifdef V4R_PHASE_CLOCKS
         if (COUNT) clk_chunk += phase_clock() - tc;
 #endif
@@ -2282,9 +2348,10 @@ int report_checks(v4r_renderer *r) {
     HIP_TRY(hipMemcpy(&failed, r->stats + 8, sizeof failed, hipMemcpyDeviceToHost));
     if (failed) {
         HIP_TRY(hipMemset(r->stats + 8, 0, sizeof failed));
-        static const char *names[] = {"stack overflow", "stack underflow", "queue index", "queue length", "ray counter", "path slot", "next ray"};
+        static const char *names[] = {"stack overflow", "stack underflow", "queue index", "queue length", "ray counter", "path slot", "next ray",
+                                      "a wave waited too long for its workgroup's next pool of rays"};
         std::string what;
-        for (int k = 0; k < 7; ++k)
+        for (int k = 0; k < 8; ++k)
             if (failed >> k & 1ull) what += std::string(what.empty() ? "" : ", ") + names[k];
         return set_error(V4R_E_HIP, "device bounds checks failed: " + what);
     }

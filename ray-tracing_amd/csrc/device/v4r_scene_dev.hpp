@@ -265,7 +265,7 @@ V4R_DEV void consider(const SceneDev &S, uint32_t prim_index, V3 o, V3 d, Best &
 // not followed; its check's bit is raised in a device word that the host reads after the job and turns into an error.
 // `V4R_CHECK(errors, code, condition)` is true when the access may go ahead; without the flag it is the constant true.
 enum : int { CHECK_STACK_OVERFLOW = 0, CHECK_STACK_UNDERFLOW = 1, CHECK_QUEUE_INDEX = 2, CHECK_QUEUE_LENGTH = 3, CHECK_RAY_COUNTER = 4,
-             CHECK_PATH_SLOT = 5, CHECK_NEXT_RAY = 6 };
+             CHECK_PATH_SLOT = 5, CHECK_NEXT_RAY = 6, CHECK_POOL_WAIT = 7 };
 #ifdef V4R_DEBUG_CHECKS
 #define V4R_CHECK(errors, code, condition) ((condition) ? true : (atomicOr((errors), 1ull << (code)), false))
 #else
