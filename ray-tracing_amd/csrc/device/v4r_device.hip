@@ -343,6 +343,7 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
     // and the one whose last groups are still being traced) in two sets of LDS; a set is reused two pools later, after its
     // pool's entries are written.  s_next[set] packs the pool's sequence number, its number of groups and the next group to hand
     // out into one word, so that one LDS atomic tells a wave all three consistently, whichever pool lives in the set by then.
+    static_assert(RAYS_PER_THREAD * BLOCK / 64 <= 31 && RAYS_PER_THREAD * BLOCK <= 1024, "a pool's groups fit 5 bits of s_next, a rank 10 bits of s_where");
     constexpr uint32_t WHERE_NONE = 0xFFFFu;  // s_where: destination << 10 | rank among the pool's rays with that destination
     constexpr uint32_t SPIN_LIMIT = 1u << 22;  // (a wave that waited this long for another gives the launch up: the checked build reports it)
     auto pack_next = [](uint32_t seq, uint32_t n_groups) { return (seq << 17) | (n_groups << 12); };
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
                         s_pool[p ^ 1u][1] = nc;
                         s_free[p ^ 1u] = 0u;
                         __hip_atomic_store(&s_next[p ^ 1u], pack_next((seq + 1u) & 0x7FFFu, (nc + 63u) / 64u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_store(&s_current, seq + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_store(&s_current, (seq + 1u) & 0x7FFFu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
             } else {  // another wave is opening the next pool
