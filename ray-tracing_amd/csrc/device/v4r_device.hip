@@ -7,7 +7,7 @@
 //                                  kernels filled.  4-wide BVH traversal + closest hit; a miss writes
 //                                  the path's radiance (background); a hit is ranked within its
 //                                  material class in LDS and its ray index is appended to the class
-//                                  queue (one global atomic per class per 1024-ray chunk)
+//                                  queue (one global atomic per class per 1024-ray pool)
 //     k_shade<class>(s)            per-class material evaluation; the scattered ray goes to slot
 //                                  class_base + i of the other ray queue (no atomics)
 //   k_resolve                      per-pixel sum of the batch's path radiances into the accumulator
@@ -53,7 +53,7 @@ constexpr int TRACE_RAYS_PER_THREAD = V4R_TRACE_RAYS_PER_THREAD;
 // Per-segment queue counters, zeroed once per batch.
 struct SegCtr {
     uint32_t given_up;      // rays the first trace launch of the segment left for the second
-    uint32_t trace_cursor;  // next chunk of the ray queue that a workgroup of the first launch takes
+    uint32_t trace_cursor;  // next pool of the ray queue that a workgroup of the first launch takes
     uint32_t hit_count[CLS_COUNT];
     uint32_t second_cursor;  // trace_cursor of the second launch
     uint32_t pad[7];
@@ -251,17 +251,18 @@ V4R_DEV void stage_tree_top(const SceneDev &S, v4f *s_top, Stack &st) {
     st.n_top = S.n_top_nodes;
 }
 
-// BVH traversal + closest hit for the rays of one segment.  A workgroup takes RAYS_PER_THREAD*256 rays
-// at a time (the chunk at its own grid position first, then chunks from a shared cursor: one global
-// atomic per chunk); each lane traces RAYS_PER_THREAD rays of the chunk one after the other.  Within a
+// BVH traversal + closest hit for the rays of one segment.  A workgroup takes a pool of RAYS_PER_THREAD*256 rays
+// at a time (the one at its own grid position first, then pools from a shared cursor: one global
+// atomic per pool) and hands it out to its waves in groups of 64 rays; a wave that is done with its group takes
+// the next one, so no wave waits for another.  Within a
 // wave the traversal alternates, by vote, between stepping through interior nodes and intersecting the
-// leaves that lanes have parked.  A hit is ranked within its shading class in LDS; when the chunk is
-// done the workgroup reserves its slots in each class queue with one global atomic per class and
-// copies the ray + hit records there.  (Letting a lane start its next ray while its neighbours are
+// leaves that lanes have parked.  A hit is ranked within its shading class in LDS; the wave that finishes a pool's
+// last group reserves the pool's slots in each class queue with one global atomic per class and
+// writes the rays' indices there.  (Letting a lane start its next ray while its neighbours are
 // still inside the previous one -- rays handed out by an LDS ticket counter, the next ray kept
 // preloaded in registers -- was measured: it removes 12 % of the wave-level node steps on the sphere
 // scenes and 46 % on the bunny scene, but its extra votes and low-occupancy set-up code made all but
-// the bunny scene 5-20 % slower, so rays are assigned statically.)
+// the bunny scene 5-20 % slower, so a wave's 64 lanes start their rays together.)
 #ifndef V4R_TRACE_MIN_WAVES
 #define V4R_TRACE_MIN_WAVES 5  // 94-98 VGPRs unforced; the 8-wide tree's later segments run six waves (80 VGPRs, 28 B of scratch): TREE_8_WIDE_DENSE
 #endif
@@ -286,7 +287,7 @@ struct PrimaryArgs {
     RayOrder order;         // over the band
 };
 // A segment is traced by up to two launches.  In the first, a wave that is down to `give_up_lanes`
-// traversing lanes gives those rays up (their indices go to Q.given_up, through the same chunk-level
+// traversing lanes gives those rays up (their indices go to Q.given_up, through the same pool-level
 // ranking as the hits); the second launch (SECOND) traces the given-up rays of the whole
 // segment packed next to each other, starting from the closest hit they had found, and never gives up.
 // (SECOND is a template parameter because the extra index it carries costs the first launch an occupancy step.)
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
     __shared__ uint32_t s_pool[2][2], s_next[2], s_done[2], s_free[2], s_current, s_finished;
     __shared__ v4f s_top[8 * (WIDE8 ? TOP_NODES_8 : TOP_NODES)];
     StackT<lds_depth(WIDE8)> st;
-    stage_tree_top(S, s_top, st);  // the chunk loop below synchronises before the first traversal
+    stage_tree_top(S, s_top, st);  // (the workgroup synchronises once below, before the first traversal)
     st.lds = (lds_uint2 *)lds_stack + threadIdx.x;
     st.stride = BLOCK;
     st.spill = Q.spill + (size_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -327,8 +328,8 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
     TraceCounters cnt;
     uint32_t n_traced = 0, n_lights = 0;
     constexpr uint32_t DEST_NONE = 0xFFu;
-    // A short queue is spread over as many workgroups as possible: a thread then traces fewer rays per
-    // chunk (down to one), so the launch lasts about one ray's traversal instead of RAYS_PER_THREAD.
+    // A short queue is spread over as many workgroups as possible: the pools then hold fewer rays per thread
+    // (down to one), so the launch lasts about one ray's traversal instead of RAYS_PER_THREAD.
     const uint32_t per_thread = min((uint32_t)RAYS_PER_THREAD, max(1u, (n_in + gridDim.x * BLOCK - 1u) / (gridDim.x * BLOCK)));
     const uint32_t chunk = per_thread * BLOCK;
 #ifdef V4R_PHASE_CLOCKS
@@ -419,10 +420,9 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
 #ifdef V4R_PHASE_CLOCKS
         if (COUNT) clk_chunk += phase_clock() - tc;
 #endif
-        {
 #ifdef V4R_PHASE_CLOCKS
-            const unsigned long long ta = COUNT ? phase_clock() : 0ull;
-            wave_rays++;
+        const unsigned long long ta = COUNT ? phase_clock() : 0ull;
+        wave_rays++;
 #endif
         const uint32_t in_pool = g * 64u + lane_id();
         uint32_t pos = base + in_pool;
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
                 Q.rad[__float_as_uint(bb.z)] = make_float4(bb.w * S.bg[0], cc.x * S.bg[1], cc.y * S.bg[2], 0.0f);
             }
         }
-        // Rank of the ray among the chunk's rays with the same destination: the lanes of the wave that share a
+        // Rank of the ray among the pool's rays with the same destination: the lanes of the wave that share a
         // destination are found by ballot, one of them reserves their ranks with a single LDS atomic, and each
         // takes the rank of its position among them.
         uint32_t w = WHERE_NONE;
@@ -573,12 +573,9 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
             if (dest == which) w = (which << 10) | (first + (uint32_t)__popcll(same & ((1ull << lane_id()) - 1ull)));
             todo &= ~same;
         }
-            reinterpret_cast<uint16_t *>(s_where)[p * (RAYS_PER_THREAD * BLOCK) + in_pool] = (uint16_t)w;
+        reinterpret_cast<uint16_t *>(s_where)[p * (RAYS_PER_THREAD * BLOCK) + in_pool] = (uint16_t)w;
 #ifdef V4R_PHASE_CLOCKS
-            if (COUNT) clk_end += phase_clock() - td;
-#endif
-        }
-#ifdef V4R_PHASE_CLOCKS
+        if (COUNT) clk_end += phase_clock() - td;
         tc = COUNT ? phase_clock() : 0ull;
 #endif
         // (the atomic orders this wave's ranks and s_where entries before the count that another wave may act on)
