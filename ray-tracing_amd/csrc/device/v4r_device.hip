@@ -50,15 +50,19 @@ constexpr int BLOCK = 256;
 #endif
 constexpr int TRACE_RAYS_PER_THREAD = V4R_TRACE_RAYS_PER_THREAD;
 
-// Per-segment queue counters, zeroed once per batch.
-struct SegCtr {
-    uint32_t given_up;      // rays the first trace launch of the segment left for the second
-    uint32_t trace_cursor;  // next pool of the ray queue that a workgroup of the first launch takes
-    uint32_t hit_count[CLS_COUNT];
-    uint32_t second_cursor;  // trace_cursor of the second launch
-    uint32_t pad[7];
+// Per-segment queue counters, zeroed once per batch.  Every counter has a 64-byte line of its own: each pool of a trace launch
+// ends with one atomic on every one of them, and atomics on one line are served one after the other.
+struct alignas(64) CounterLine {
+    uint32_t v;
+    uint32_t pad[15];
 };
-static_assert(sizeof(SegCtr) == 64, "SegCtr is one 64-byte line");
+struct SegCtr {
+    CounterLine given_up;      // rays the first trace launch of the segment left for the second
+    CounterLine trace_cursor;  // next pool of the ray queue that a workgroup of the first launch takes
+    CounterLine second_cursor;  // trace_cursor of the second launch
+    CounterLine hit_count[CLS_COUNT];
+};
+static_assert(sizeof(SegCtr) == 64 * (3 + CLS_COUNT), "one line per counter");
 
 struct Queues {
     float4 *ray[2][3];          // [segment parity][column]: {o.xyz,d.x} {d.yz,slot,thr.r} {thr.gb,k0,k1}
@@ -225,7 +229,7 @@ V4R_DEV uint32_t rays_in(const Queues &Q, uint32_t seg) {
     uint32_t n = 0;
 #pragma unroll
     for (int k = 0; k < CLS_COUNT; ++k)
-        if (k != CLS_LIGHT) n += prev.hit_count[k];
+        if (k != CLS_LIGHT) n += prev.hit_count[k].v;
     return n;
 }
 // Position of class `cls` inside the ray queue that the shading kernels of segment `seg` fill: the
@@ -235,7 +239,7 @@ V4R_DEV uint32_t class_base(const Queues &Q, uint32_t seg, int cls) {
     uint32_t n = 0;
 #pragma unroll
     for (int k = 0; k < CLS_COUNT; ++k)
-        if (k != CLS_LIGHT && k < cls) n += c.hit_count[k];
+        if (k != CLS_LIGHT && k < cls) n += c.hit_count[k].v;
     return n;
 }
 
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
     st.spill_depth = (int)Q.spill_depth;
 #endif
     SegCtr *ctr = Q.ctr + seg;
-    uint32_t n_in = second ? ctr->given_up : (PRIMARY ? A.n_paths : rays_in(Q, seg));
+    uint32_t n_in = second ? ctr->given_up.v : (PRIMARY ? A.n_paths : rays_in(Q, seg));
     if (!V4R_CHECK(Q.stats + 8, CHECK_QUEUE_LENGTH, n_in <= Q.cap)) n_in = 0;
     float4 *const *rq = Q.ray[seg & 1u];
     const uint32_t npix = A.npix;
@@ -389,7 +393,7 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
                     __builtin_amdgcn_s_sleep(2);
                 }
                 if (!stuck && lane_id() == 0) {
-                    const uint32_t nb = gridDim.x * chunk + atomicAdd(second ? &ctr->second_cursor : &ctr->trace_cursor, chunk);
+                    const uint32_t nb = gridDim.x * chunk + atomicAdd(second ? &ctr->second_cursor.v : &ctr->trace_cursor.v, chunk);
                     const uint32_t nc = pool_count(nb);
                     if (nc == 0u) {
                         __hip_atomic_store(&s_finished, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -584,7 +588,7 @@ __global__ __launch_bounds__(BLOCK, MEDIA == MEDIA_IN_TREE ? V4R_TRACE_MIN_WAVES
             uint32_t first_of = 0u;
             if (lane_id() <= (uint32_t)CLS_COUNT) {
                 const uint32_t n = s_cnt[p][lane_id()];
-                uint32_t *total = lane_id() < (uint32_t)CLS_COUNT ? &ctr->hit_count[lane_id()] : &ctr->given_up;
+                uint32_t *total = lane_id() < (uint32_t)CLS_COUNT ? &ctr->hit_count[lane_id()].v : &ctr->given_up.v;
                 first_of = n ? atomicAdd(total, n) : 0u;
                 s_cnt[p][lane_id()] = 0u;
             }
@@ -760,7 +764,7 @@ V4R_DEV bool shade_hit(const SceneDev &S, const Queues &Q, const PathState &p, f
 template <int CLS, bool COUNT, bool NOISE>
 __global__ __launch_bounds__(BLOCK, NOISE ? V4R_SHADE_MIN_WAVES_NOISE : 1) void k_shade(SceneDev S, Queues Q, uint32_t seg) {
     SegCtr *ctr = Q.ctr + seg;
-    uint32_t n_in = ctr->hit_count[CLS];
+    uint32_t n_in = ctr->hit_count[CLS].v;
     if (!V4R_CHECK(Q.stats + 8, CHECK_QUEUE_LENGTH, n_in <= Q.cap)) n_in = 0;
     const uint32_t *hq = Q.hit[CLS];
     float4 *const *rq = Q.ray[seg & 1u];  // the rays k_trace just traced; the survivors go to the other queue
@@ -844,7 +848,7 @@ __global__ __launch_bounds__(BLOCK, NOISE ? V4R_TAIL_MIN_WAVES_NOISE : 1) void k
     uint32_t n_traced = 0, n_shaded = 0, texel_fetches = 0;
     // A wave keeps its lanes busy: whenever paths have ended, the free lanes take the next rays of the queue
     // (one atomic per wave and refill), so a wave is not held by its longest path while the queue has rays.
-    uint32_t *cursor = &Q.ctr[seg0].trace_cursor;  // no k_trace launch uses the cursor of this segment
+    uint32_t *cursor = &Q.ctr[seg0].trace_cursor.v;  // no k_trace launch uses the cursor of this segment
     bool alive = false, queue_empty = false;
     PathState p;
     p.o = p.d = p.thr = v3(0, 0, 0);
