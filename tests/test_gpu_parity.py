@@ -481,6 +481,30 @@ def test_batches_and_single_passes_are_bit_identical():
     r.close()
 
 
+@pytest.mark.parametrize("size", [(63, 1), (64, 1), (65, 1), (1023, 1), (1024, 1), (1025, 1), (257, 255)])
+def test_queue_lengths_around_a_group_and_a_pool(size):
+    """A trace launch hands its queue out in pools of up to 1024 rays and groups of 64: queues one ray short of, equal to and one
+    ray past those sizes (and, with 7 passes in one job, 7 times as long, cut at other places) give the oracle's image, and
+    one job of 7 passes equals 7 jobs of one pass bit for bit."""
+    scene = scenes.load("c3", *size)
+    r = Renderer(scene.renderer_param, scene.camera_param, scene)
+    r.render_passes(7)
+    a, n = r.read_accumulator()
+    assert n == 7
+    r.clear()
+    for p in range(7):
+        r.render_passes(1, first_pass=p)
+    b, _ = r.read_accumulator()
+    assert np.array_equal(a, b)
+    img_o, _ = oracle.render(r.desc, 7, seed=r.seed)
+    far = np.abs(a - img_o).max(axis=2) >= 2e-3 * (np.abs(img_o).max(axis=2) + 0.07)
+    assert far.sum() <= max(2, 0.003 * far.size), int(far.sum())   # (paths whose discrete decisions a rounding flipped)
+    prim_d, t_d = r.trace_primary()
+    prim_o, t_o = oracle.trace_primary(r.desc)
+    assert np.array_equal(prim_d, prim_o)
+    r.close()
+
+
 @pytest.mark.parametrize("size,spp", [((37, 23), 21), ((8, 8), 70), ((5, 3), 3), ((64, 33), 16)])
 def test_ray_order_covers_every_pixel_and_pass(size, spp):
     """The camera rays of a batch are queued tile by tile (pixels x passes), with leftover pixels and
