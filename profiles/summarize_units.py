@@ -26,7 +26,7 @@ def totals(pattern):
 
 
 res = {}
-for which in ("active", "detail"):
+for which in ("active", "detail", "l1a", "l1b", "l1c"):
     for k, c in totals(os.path.join(root, which, "**", "*_counter_collection.csv")).items():
         if not k.startswith("k_"):
             continue
@@ -36,6 +36,9 @@ for which in ("active", "detail"):
             if name == "GRBM_GUI_ACTIVE":
                 continue
             e[name] = v
-            if gui and ("CYCLES" in name or "ACTIVE" in name or "WAIT" in name or "FULL" in name or "CONFLICT" in name):
-                e[name + "_x4_per_simd_cycle"] = round(v * 4 / (SIMDS * gui), 4)
+            if gui and ("CYCLES" in name or "ACTIVE" in name or "WAIT" in name or "FULL" in name or "CONFLICT" in name or "STALL" in name or "BUSY" in name or "GATE" in name or "LATENCY" in name):
+                if name.startswith("SQ_"):
+                    e[name + "_x4_per_simd_cycle"] = round(v * 4 / (SIMDS * gui), 4)
+                elif "LATENCY" not in name:
+                    e[name + "_per_cu_cycle"] = round(v / (256 * gui), 4)  # (_sum counters: summed over the 256 compute units)
 json.dump(res, sys.stdout, indent=1)
